@@ -1,0 +1,148 @@
+"""Capture golden vectors from the REFERENCE itself (run in the build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference through tests/golden/_ref_harness.py (I/O stubs + diffusers
+stand-in), fills every reference module with the procedural
+name-keyed weights of serenade_amd/utils/synth.py (seed 0) and stores inputs and
+outputs as small .npz fixtures next to this file.  The reference's files never
+travel; only these vectors do.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_harness  # noqa: E402
+
+_ref_harness.install()
+
+from serenade.models import Serenade  # noqa: E402
+from serenade.utils.masking import make_non_pad_mask, make_pad_mask  # noqa: E402
+from serenade.vocoder.models.hifigan import HiFiGANGenerator  # noqa: E402
+
+from serenade_amd.utils.synth import (HIFIGAN_PARAMS, SERENADE_PARAMS, fill_state_dict,  # noqa: E402
+                                      synth_inputs)
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: tuple(np.shape(v)) for k, v in out.items()})
+
+
+def rnd(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+
+
+def main():
+    model = Serenade(**SERENADE_PARAMS).eval()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    est = model.cfm_decoder.estimator
+    rng = np.random.default_rng(777)
+
+    # ---- a6 masks
+    npz("masks", lengths=np.array([5, 3, 2]), pad=make_pad_mask([5, 3, 2]),
+        non_pad=make_non_pad_mask([5, 3, 2]))
+
+    # ---- a2 encoder (odd and tiny lengths; reflection pad needs T > 3)
+    x = rnd(rng, 2, 33, 768)
+    npz("encoder", x=x, y=model.encoder(x, None))
+
+    # ---- a5 GST
+    sp = rnd(rng, 2, 70, 80)
+    ref_embs = model.gst.ref_enc(sp)
+    npz("gst", speech=sp, ref_embs=ref_embs, style=model.gst(sp))
+
+    # ---- a4.x UNet pieces, full width, tiny length, padded batch + odd L
+    for tag, L, lens in (("L48", 48, [48, 37]), ("L65", 65, [65, 50])):
+        B = 2
+        mask = make_non_pad_mask(lens).unsqueeze(1)
+        xin = rnd(rng, B, 80, L)
+        mu = rnd(rng, B, 162, L)
+        spk = rnd(rng, B, 256)
+        t = torch.tensor(0.3)
+        temb = est.time_mlp(est.time_embeddings(t))
+        h = torch.cat([xin, mu], dim=1)
+        rb = est.down_blocks[0][0]
+        b1 = rb.block1(h, mask)
+        r1 = rb(h, mask, temb, spk)
+        tb = est.down_blocks[0][1][0]
+        t1 = tb(hidden_states=r1.transpose(1, 2), attention_mask=mask[:, 0, :], timestep=temb,
+                speaker_features=spk)
+        out = est(xin, mask, mu, t, spk)
+        npz("decoder_" + tag, lens=np.array(lens), x=xin, mu=mu, spk=spk, t=t, temb=temb, block1=b1,
+            resnet=r1, tfm=t1, out=out)
+
+    # ---- a3 Euler loop with per-step trace (explicit noise)
+    L, lens = 48, [48, 37]
+    mask = make_non_pad_mask(lens).unsqueeze(1)
+    mu = rnd(rng, 2, 162, L)
+    spk = rnd(rng, 2, 256)
+    z = rnd(rng, 2, 80, L) * 0.667
+    cfm = model.cfm_decoder
+    t_span = torch.linspace(0, 1, 11)
+    # replicate solve_euler but keep the per-step states (flow_matching.py:79-93)
+    tt, dt = t_span[0], t_span[1] - t_span[0]
+    xs, cur = [], z
+    for step in range(1, len(t_span)):
+        cur = cur + dt * est(cur, mask, mu, tt, spk)
+        tt = tt + dt
+        xs.append(cur)
+        if step < len(t_span) - 1:
+            dt = t_span[step + 1] - tt
+    final = cfm.solve_euler(z, t_span=t_span, mu=mu, mask=mask, trg_spks=spk)
+    assert torch.equal(final, xs[-1])
+    npz("euler_L48", lens=np.array(lens), mu=mu, spk=spk, z=z, trace=torch.stack(xs), out=final)
+
+    # ---- a1 full inference chain, B = 1, explicit z via patched randn
+    d = synth_inputs(1, 64, T_ref=16, seed=4321)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: d["z"] / 0.667
+    try:
+        mel = model.inference(d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
+                              d["ref_logmel"], d["ref_midi"], d["ref_lft"])
+    finally:
+        torch.randn = orig
+    # padded batch B = 2 through the same entry point
+    d2 = synth_inputs(2, 40, T_ref=16, seed=4322, lengths=[40, 29])
+    torch.randn = lambda *a, **k: d2["z"] / 0.667
+    try:
+        mel2 = model.inference(d2["x"], d2["lengths"], d2["midi"], d2["lft"], d2["ref_x"], d2["ref_lengths"],
+                               d2["ref_logmel"], d2["ref_midi"], d2["ref_lft"])
+    finally:
+        torch.randn = orig
+    npz("inference", mel_b1=mel, mel_b2=mel2)
+
+    # ---- a8 HiFi-GAN + a7 Vocoder arithmetic
+    gen = HiFiGANGenerator(**HIFIGAN_PARAMS).eval()
+    gen.load_state_dict(fill_state_dict(gen.state_dict(), seed=0))
+    gen.remove_weight_norm()
+    c = rnd(rng, 2, 80, 12)
+    y = gen(c)
+    y1 = gen.inference(mel)  # (T*240, 1) from the B = 1 chain above
+    npz("hifigan", c=c, y=y, wave_b1=y1.view(-1))
+    # small-channel variant (exercises other widths / scales, default ctor kernel sizes)
+    small = dict(HIFIGAN_PARAMS, channels=64, upsample_scales=(4, 2), upsample_kernel_sizes=(8, 4),
+                 resblock_kernel_sizes=(3, 5), resblock_dilations=[(1, 2), (2, 6, 3)])
+    gs = HiFiGANGenerator(**small).eval()
+    gs.load_state_dict(fill_state_dict(gs.state_dict(), seed=1))
+    gs.remove_weight_norm()
+    cs = rnd(rng, 1, 80, 9)
+    npz("hifigan_small", c=cs, y=gs(cs))
+
+
+if __name__ == "__main__":
+    main()
