@@ -1,0 +1,165 @@
+/*
+ * serenade_hip.h — C ABI of libserenade_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (imulki/serenade) is pure Python on PyTorch and has NO FFI or operator
+ * registry: its boundary is the Python class API.  This header is
+ * therefore the boundary this build defines *behind* that API: one entry point per
+ * arithmetic stage of the inference hot path, each citing the reference code it replaces.
+ * The Python mirror classes (serenade_amd.models / serenade_amd.vocoder) keep the
+ * reference's signatures and state_dict layout and call only these functions.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (fp32 unless noted), borrowed for the call only;
+ *   - activations are channels-last: (batch, time, channels), channels contiguous;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, negative on error; srn_last_error() gives the message
+ *     (thread-local).  No allocation, no global mutable state, re-entrant.
+ */
+#ifndef SERENADE_HIP_H
+#define SERENADE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRN_ABI_VERSION 1
+#define SRN_MAX_TAPS 16
+
+/* prologue activation applied to the gathered input elements */
+enum { SRN_ACT_NONE = 0, SRN_ACT_LEAKY = 1, SRN_ACT_SILU = 2, SRN_ACT_MISH = 3 };
+/* residual mode */
+enum { SRN_RES_NONE = 0, SRN_RES_ADD = 1, SRN_RES_AXPY = 2 };
+/* post op */
+enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2 };
+
+/*
+ * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors, computed with the exact-fp32
+ * MFMA (v_mfma_f32_32x32x2_f32):
+ *
+ *   out[z, t*out_t_stride + out_t_off, n] = epilogue( alpha * sum_{tap, c} w[n, tap*C_in + c] *
+ *                                  act( in[z, t*in_stride + tap_off[tap], c] ) + bias[n] )
+ *
+ * Covers, with different parameters, every contraction on the hot path:
+ *   Conv1d k3/k7/k11 (+dilation, stride 2, zero or reflect padding)   decoder.py:70,107,271,335;
+ *                                                                      serenade.py:282-294,366-373;
+ *                                                                      hifigan.py:71-77,140-148; residual_block.py:187-226
+ *   ConvTranspose1d (one call per output phase)                        decoder.py:191; hifigan.py:96-104
+ *   Conv1d k1 / nn.Linear                                              decoder.py:90,341; transformer.py:120-138
+ *   QK^T and PV of the self-attention (batched over batch x heads)     transformer.py:292-301 (diffusers Attention)
+ * Input rows t >= len_in[zb] are read as zero (the reference's `x * mask`), rows outside
+ * [0, T_in) are zero or reflected.  The input may be the channel-concatenation of two tensors
+ * (decoder.py:405,449 `pack([x, skip])`) without materialising it.
+ */
+typedef struct SrnConvParams {
+  int32_t n_batch;   /* z range = n_batch * n_head */
+  int32_t n_head;    /* >= 1; z -> (zb = z / n_head, zh = z % n_head) */
+  int32_t T_in, T_out;
+  int32_t C_in;      /* channels per tap seen by the input gather (multiple of 4) */
+  int32_t C_in0;     /* channels taken from in0; the remaining C_in - C_in0 come from in1 (multiple of 32 if < C_in) */
+  int32_t C_w;       /* valid k per tap on the weight side (<= C_in; = C_in normally) */
+  int32_t N;         /* GEMM N (weight rows) */
+  int32_t N_out;     /* stored output channels (N, or N/2 for GEGLU) */
+  int32_t n_taps;
+  int32_t tap_off[SRN_MAX_TAPS];
+  int32_t in_stride;
+  int32_t pad_reflect; /* 0: zero padding, 1: reflection */
+  int32_t w_nmajor;    /* 0: w is [N][n_taps*C_in] (k contiguous); 1: w is [K][N] (n contiguous), n_taps == 1 */
+  int32_t pro_act;
+  float pro_slope;
+  float alpha;
+  float beta;        /* SRN_RES_AXPY: out = res + beta * val */
+  int32_t geglu;     /* 1: weight rows interleaved in 32-row (value | gate) groups, out = value * gelu(gate) */
+  int32_t res_mode;
+  int32_t post;
+  float post_div;
+  int32_t out_t_stride, out_t_off;
+  int32_t tile;      /* 0 = auto, else a tile-config id (see conv_gemm.hip) */
+  const float* in0; int64_t in0_bs, in0_hs; int32_t ld_in0;
+  const float* in1; int64_t in1_bs; int32_t ld_in1;
+  const float* w;   int64_t w_bs, w_hs; int32_t ldw;
+  const float* bias;
+  const int32_t* len_in;   /* per zb, or NULL */
+  const int32_t* len_out;  /* per zb, or NULL: output rows t >= len_out are multiplied by 0 */
+  const float* res;  int64_t res_bs; int32_t ld_res;
+  const float* res2; int64_t res2_bs; int32_t ld_res2;  /* second additive residual (HiFi-GAN stage sum) */
+  float* out; int64_t out_bs, out_hs; int32_t ld_out;
+  float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */
+} SrnConvParams;
+
+int srn_abi_version(void);
+const char* srn_last_error(void);
+
+/* the workhorse above */
+int srn_conv_gemm(const SrnConvParams* p, void* stream);
+
+/*
+ * GroupNorm(8 groups, eps) -> Mish -> (+ time_bias[c]) -> * mask   (Block1D tail + the time-embedding add of
+ * ResnetBlock1D; decoder.py:71-77,96-97).  Statistics come from the per-tile partials written by
+ * srn_conv_gemm and run over the full padded length T (as the reference's GroupNorm does).
+ *   x, y: (B, T, C); gamma, beta: (C); time_bias: (C) at time_bias + b * time_bias_bs, or NULL; lens: (B) or NULL.
+ */
+int srn_gn_mish_apply(const float* x, const float* gn_partials, const float* gamma, const float* beta,
+                      const float* time_bias, int64_t time_bias_bs, const int32_t* lens, float* y, int B, int T,
+                      int C, int groups, float eps, void* stream);
+
+/*
+ * Tail of ResnetBlock1D (decoder.py:98-101, 34-45):
+ *   v = Mish(GroupNorm(c2)) * mask + r ;  y = (v - mean_c) / sqrt(var_c + eps) * scale[b] + shift[b]
+ * c2, r, y: (B, T, C); scale, shift: row b at scale + b * ld_ss (C values each).
+ */
+int srn_resblock_tail(const float* c2, const float* gn_partials, const float* gamma, const float* beta,
+                      const int32_t* lens, const float* r, const float* scale, const float* shift, int64_t ld_ss,
+                      float* y, int B, int T, int C, int groups, float gn_eps, float ln_eps, void* stream);
+
+/* nn.LayerNorm over the last dim (transformer.py:211,249): x, y (rows, C). */
+int srn_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
+                  void* stream);
+
+/*
+ * Row softmax of attention scores with a key-padding mask (F.scaled_dot_product_attention semantics at
+ * transformer.py:292-301): s (Z, L, ld) in place; keys k >= lens[z / n_head] get probability 0;
+ * columns [L, ld) are written as 0.
+ */
+int srn_softmax_rows(float* s, const int32_t* lens, int Z, int n_head, int L, int ld, void* stream);
+
+/* SinusoidalPosEmb (decoder.py:54-63): out row i (stride ld) = [sin(scale*t_i*f_k), cos(scale*t_i*f_k)], t (n) on device. */
+int srn_sinusoidal_emb(const float* t, float* out, int n, int dim, int ld, float scale, void* stream);
+
+/* Generic channels-last copy with channel offset/strides: dst[b,t,dc0+c] = src[b,t,sc0+c] * a + bvec?  (pack/concat) */
+int srn_copy_channels(const float* src, int64_t src_bs, int ld_src, int sc0, float* dst, int64_t dst_bs, int ld_dst,
+                      int dc0, int B, int T, int C, void* stream);
+
+/* (B, C, T) <-> (B, T, C) transposes at the API edge (reference tensors are (B, C, T); decoder.py:405-467). */
+int srn_transpose_ct(const float* src, float* dst, int B, int R, int Cc, int64_t src_bs, int ld_src, int64_t dst_bs,
+                     int ld_dst, void* stream);
+
+/* y = (x * a[c] + b[c] - c[c]) / d[c] (Vocoder.decode normalisation, vocoder.py:52-56); x, y (rows, C). */
+int srn_renorm(const float* x, const float* trg_scale, const float* trg_mean, const float* voc_mean,
+               const float* voc_scale, float* y, int64_t rows, int C, void* stream);
+
+/* HiFi-GAN output stage: LeakyReLU(slope) -> Conv1d(C -> 1, k, pad (k-1)/2) -> tanh  (hifigan.py:137-149).
+ * x (B, T, C) channels-last, w (k, C), y (B, T). */
+int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int k,
+                      float slope, void* stream);
+
+/* GST reference encoder layer: Conv2d(k3, s2, p1, no bias) + BatchNorm2d(eval) + ReLU (style_encoder.py:142-154),
+ * NHWC: x (B, H, W, Ci) -> y (B, Ho, Wo, Co); w (Co, 3, 3, Ci); bn_scale/bn_shift (Co) = folded running stats. */
+int srn_conv2d_bn_relu(const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y, int B,
+                       int H, int W, int Ci, int Co, void* stream);
+
+/* torch.nn.GRU last hidden state (style_encoder.py:169,188-189): xs (B, T, I) -> h (B, H); gates r,z,n. */
+int srn_gru_last(const float* xs, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* h,
+                 int B, int T, int I, int H, void* stream);
+
+/* StyleTokenLayer (style_encoder.py:235-252 + gst/attention.py:110-184,298-300): q (B, Dq) -> out (B, F).
+ * embs (n_tok, dk_in) raw (tanh applied inside). */
+int srn_style_token_attention(const float* ref, const float* embs, const float* wq, const float* bq, const float* wk,
+                              const float* bk, const float* wv, const float* bv, const float* wo, const float* bo,
+                              float* out, int B, int Dq, int n_tok, int dk_in, int F, int n_head, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of libserenade_hip.so (the C ABI declared in include/serenade_hip.h).
+
+There is no fallback: if the library cannot be loaded the product path raises.  The CPU
+oracle under ``oracle/`` is never imported from here.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libserenade_hip.so")
+
+SRN_MAX_TAPS = 16
+ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_AXPY = 0, 1, 2
+POST_NONE, POST_DIV, POST_TANH = 0, 1, 2
+
+
+class SrnConvParams(ctypes.Structure):
+    _fields_ = [
+        ("n_batch", c_int32), ("n_head", c_int32), ("T_in", c_int32), ("T_out", c_int32),
+        ("C_in", c_int32), ("C_in0", c_int32), ("C_w", c_int32), ("N", c_int32), ("N_out", c_int32),
+        ("n_taps", c_int32), ("tap_off", c_int32 * SRN_MAX_TAPS), ("in_stride", c_int32),
+        ("pad_reflect", c_int32), ("w_nmajor", c_int32), ("pro_act", c_int32), ("pro_slope", c_float),
+        ("alpha", c_float), ("beta", c_float), ("geglu", c_int32), ("res_mode", c_int32), ("post", c_int32), ("post_div", c_float),
+        ("out_t_stride", c_int32), ("out_t_off", c_int32), ("tile", c_int32),
+        ("in0", c_void_p), ("in0_bs", c_int64), ("in0_hs", c_int64), ("ld_in0", c_int32),
+        ("in1", c_void_p), ("in1_bs", c_int64), ("ld_in1", c_int32),
+        ("w", c_void_p), ("w_bs", c_int64), ("w_hs", c_int64), ("ldw", c_int32),
+        ("bias", c_void_p), ("len_in", c_void_p), ("len_out", c_void_p),
+        ("res", c_void_p), ("res_bs", c_int64), ("ld_res", c_int32),
+        ("res2", c_void_p), ("res2_bs", c_int64), ("ld_res2", c_int32),
+        ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ld_out", c_int32),
+        ("gn_partials", c_void_p),
+    ]
+
+
+_P = c_void_p
+_SIGS = {
+    "srn_abi_version": (c_int, []),
+    "srn_last_error": (c_char_p, []),
+    "srn_conv_gemm": (c_int, [POINTER(SrnConvParams), _P]),
+    "srn_gn_mish_apply": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "srn_resblock_tail": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int,
+                                  c_float, c_float, _P]),
+    "srn_layernorm": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, _P]),
+    "srn_softmax_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "srn_sinusoidal_emb": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),
+    "srn_copy_channels": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
+    "srn_transpose_ct": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, _P]),
+    "srn_renorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "srn_out_conv_tanh": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "srn_conv2d_bn_relu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "srn_gru_last": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "srn_style_token_attention": (c_int, [_P] * 11 + [c_int] * 6 + [_P]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m serenade_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        if h.srn_abi_version() != 1:
+            raise RuntimeError("libserenade_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().srn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libserenade_hip {what} failed (rc={rc}): {msg}")

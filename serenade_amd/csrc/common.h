@@ -1,0 +1,71 @@
+// Shared host/device helpers for libserenade_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "serenade_hip.h"
+
+void srn_set_error(const char* fmt, ...);
+
+#define SRN_CHECK_ARG(cond, ...)      \
+  do {                                \
+    if (!(cond)) {                    \
+      srn_set_error(__VA_ARGS__);     \
+      return -1;                      \
+    }                                 \
+  } while (0)
+
+#define SRN_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      srn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -2;                                                                    \
+    }                                                                               \
+  } while (0)
+
+#define SRN_CHECK_LAUNCH() SRN_CHECK_HIP(hipGetLastError())
+
+// ---- device math --------------------------------------------------------------------------
+// Mish(x) = x * tanh(softplus(x)) (decoder.py:72,84).  tanh(log1p(e^x)) = n / (n + 2) with
+// n = e^x (e^x + 2): one exp, one divide, no cancellation for very negative x; softplus
+// threshold 20 as in torch (x > 20 -> x).
+__device__ __forceinline__ float srn_mish(float x) {
+  if (x > 20.0f) return x;
+  const float e = expf(x);
+  const float n = e * (e + 2.0f);
+  return x * (n / (n + 2.0f));
+}
+
+__device__ __forceinline__ float srn_silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float srn_gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float srn_act(float v, int act, float slope) {
+  switch (act) {
+    case SRN_ACT_LEAKY: return v > 0.0f ? v : v * slope;
+    case SRN_ACT_SILU: return srn_silu(v);
+    case SRN_ACT_MISH: return srn_mish(v);
+    default: return v;
+  }
+}
+
+// 64-lane wavefront all-reduce (sum) through cross-lane shuffles.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,408 @@
+// conv_gemm.hip — generalised implicit-GEMM conv1d / linear / batched GEMM for gfx950 (CDNA4),
+// exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain).
+//
+// Layout: activations channels-last (z, t, c) so that a GEMM row (one frame) is one contiguous
+// channel vector: the A tile of a conv tap is a run of consecutive, shifted frames — coalesced
+// 128-B row segments, no im2col.  Weights are pre-packed [n][tap][c] (k contiguous) or, for the
+// P·V product of attention, [k][n].
+//
+// Tiling: 256 threads = 4 wave64s per workgroup, BK = 32.  A/B tiles are staged through LDS with a
+// 4-float row pad (144-B rows: ds_read_b128 of 16 distinct rows hits 16 distinct 4-bank slots), double
+// buffered, with the next tile's global loads issued before the MFMA phase and written to LDS after it
+// (issue-early / write-late).  Each lane reads 4 consecutive k per ds_read_b128; MFMA step s pairs
+// k = 8*kk + s (lanes 0-31) with k = 8*kk + 4 + s (lanes 32-63) for A and B alike.
+// The blockIdx -> tile map is XCD-aware (blocks that share an A tile land on one XCD's L2).
+//
+// Reference code this replaces: see include/serenade_hip.h (SrnConvParams).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // padded LDS row (floats)
+
+template <int BM_, int BN_, int WM_, int WN_, bool NMAJ_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr bool NMAJ = NMAJ_;
+  static constexpr int MT = WM / 32, NT = WN / 32;
+  static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static constexpr int LDN = BN + 4;  // n-major B tile row (floats)
+  static constexpr int A_STAGE = BM * LDK;
+  static constexpr int B_STAGE = NMAJ ? BK * LDN : BN * LDK;
+  static constexpr int SMEM_BYTES = 2 * (A_STAGE + B_STAGE) * (int)sizeof(float);
+  static constexpr int A_LD = BM / 32;  // float4 loads per thread per stage
+  static constexpr int B_LD = BN / 32;
+};
+
+__device__ __forceinline__ float4 act4(float4 v, int act, float slope) {
+  if (act != SRN_ACT_NONE) {
+    v.x = srn_act(v.x, act, slope);
+    v.y = srn_act(v.y, act, slope);
+    v.z = srn_act(v.z, act, slope);
+    v.w = srn_act(v.w, act, slope);
+  }
+  return v;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const SrnConvParams p, const int m_tiles,
+                                                        const int n_tiles) {
+  constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * C::A_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // XCD-aware, bijective blockIdx -> logical tile id (blocks b, b+8, ... share an XCD).
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nt_i = logical % n_tiles;
+  const int rest = logical / n_tiles;
+  const int mt_i = rest % m_tiles;
+  const int z = rest / m_tiles;
+  const int zb = z / p.n_head;
+  const int zh = z - zb * p.n_head;
+  const int t0 = mt_i * BM;
+  const int n0 = nt_i * BN;
+
+  const float* __restrict__ in0 = p.in0 + (int64_t)zb * p.in0_bs + (int64_t)zh * p.in0_hs;
+  const float* __restrict__ in1 = p.in1 ? p.in1 + (int64_t)zb * p.in1_bs : nullptr;
+  const float* __restrict__ wgt = p.w + (int64_t)zb * p.w_bs + (int64_t)zh * p.w_hs;
+  const int T_in = p.T_in;
+  int len_in = T_in;
+  if (p.len_in) len_in = min(p.len_in[zb], T_in);
+
+  const int n_chunks = (p.C_in + BK - 1) / BK;
+  const int n_steps = p.n_taps * n_chunks;
+
+  // ---- per-thread load coordinates
+  const int c4 = tid & 7;    // float4 column inside the 32-wide k chunk
+  const int lrow = tid >> 3;  // 0..31
+  int a_tb[C::A_LD];          // input row before the tap offset, or INT_MIN/2 if the output row is invalid
+#pragma unroll
+  for (int i = 0; i < C::A_LD; ++i) {
+    const int t = t0 + lrow + 32 * i;
+    a_tb[i] = (t < p.T_out) ? t * p.in_stride : -(1 << 29);
+  }
+
+  float4 pa[C::A_LD];
+  float4 pb[C::B_LD];
+
+  auto load_step = [&](int step) {
+    const int tap = step / n_chunks;
+    const int chunk = step - tap * n_chunks;
+    const int ch = chunk * BK + c4 * 4;
+    const int toff = p.tap_off[tap];
+    // A: gathered, masked, activated input rows
+    {
+      const float* src = in0;
+      int ld = p.ld_in0;
+      int c = ch;
+      if (ch >= p.C_in0) {
+        src = in1;
+        ld = p.ld_in1;
+        c = ch - p.C_in0;
+      }
+      const bool cok = ch < p.C_in;
+#pragma unroll
+      for (int i = 0; i < C::A_LD; ++i) {
+        int ti = a_tb[i] + toff;
+        if (p.pad_reflect) {
+          if (ti < 0 && ti > -(1 << 28)) ti = -ti;
+          if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && ti >= 0 && ti < len_in) {
+          v = *reinterpret_cast<const float4*>(src + (int64_t)ti * ld + c);
+          v = act4(v, p.pro_act, p.pro_slope);
+        }
+        pa[i] = v;
+      }
+    }
+    // B: weights
+    if constexpr (!C::NMAJ) {
+      const bool kok = ch < p.C_w;
+      const int64_t kcol = (int64_t)tap * p.C_in + ch;
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kok && n < p.N) v = *reinterpret_cast<const float4*>(wgt + (int64_t)n * p.ldw + kcol);
+        pb[i] = v;
+      }
+    } else {
+      constexpr int F4_PER_ROW = BN / 4;
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) {
+        const int f = tid + i * 256;
+        const int krow = f / F4_PER_ROW;
+        const int n = n0 + (f % F4_PER_ROW) * 4;
+        const int k = chunk * BK + krow;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < p.C_w && n < p.N) v = *reinterpret_cast<const float4*>(wgt + (int64_t)k * p.ldw + n);
+        pb[i] = v;
+      }
+    }
+  };
+
+  auto store_step = [&](int stage) {
+    float* a = As + stage * C::A_STAGE;
+    float* b = Bs + stage * C::B_STAGE;
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i)
+      *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDK + c4 * 4) = pa[i];
+    if constexpr (!C::NMAJ) {
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i)
+        *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDK + c4 * 4) = pb[i];
+    } else {
+      constexpr int F4_PER_ROW = BN / 4;
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) {
+        const int f = tid + i * 256;
+        *reinterpret_cast<float4*>(b + (f / F4_PER_ROW) * C::LDN + (f % F4_PER_ROW) * 4) = pb[i];
+      }
+    }
+  };
+
+  // ---- accumulators
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int wm0 = (wave / C::WAVES_N) * C::WM;
+  const int wn0 = (wave % C::WAVES_N) * C::WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  load_step(0);
+  store_step(0);
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < n_steps) load_step(step + 1);  // global loads in flight under the MFMAs
+
+    const float* a = As + cur * C::A_STAGE + (wm0 + li) * LDK + 4 * lh;
+    const float* b = C::NMAJ ? Bs + cur * C::B_STAGE + (4 * lh) * C::LDN + wn0 + li
+                             : Bs + cur * C::B_STAGE + (wn0 + li) * LDK + 4 * lh;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 af[MT], bf[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a + m * 32 * LDK + kk * 8);
+      if constexpr (!C::NMAJ) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b + n * 32 * LDK + kk * 8);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float* bp = b + (kk * 8) * C::LDN + n * 32;
+          bf[n] = make_float4(bp[0], bp[C::LDN], bp[2 * C::LDN], bp[3 * C::LDN]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+        }
+    }
+    if (step + 1 < n_steps) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  // no __restrict__ here: res / res2 may alias out (in-place Euler update, HiFi-GAN stage sum)
+  float* out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs;
+  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs : nullptr;
+  const float* res2 = p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
+  int len_out = p.T_out;
+  if (p.len_out) len_out = min(p.len_out[zb], p.T_out);
+  const int gn_mt = (p.T_out + 31) / 32;
+  const int gn_nt = p.N / 32;
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (p.geglu && (n & 1)) continue;  // gate tiles are consumed with their value tile
+      const int ncol = n0 + wn0 + n * 32 + li;  // GEMM column
+      int ocol = ncol;
+      float bias_v = 0.f, bias_g = 0.f;
+      bool col_ok = ncol < p.N;
+      if (p.geglu) {
+        ocol = ((n0 + wn0 + n * 32) >> 6) * 32 + li;
+        if (p.bias && col_ok) {
+          bias_v = p.bias[ncol];
+          bias_g = p.bias[ncol + 32];
+        }
+      } else if (p.bias && col_ok) {
+        bias_v = p.bias[ncol];
+      }
+      col_ok = col_ok && ocol < p.N_out;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = t0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = col_ok && trow < p.T_out;
+        float v = acc[m][n][r] * p.alpha + bias_v;
+        if constexpr (NT % 2 == 0) {
+          if (p.geglu) {
+            const float g = acc[m][(n + 1) % NT][r] * p.alpha + bias_g;
+            v = v * srn_gelu_erf(g);
+          }
+        }
+        if (trow >= len_out) v = 0.f;
+        if (ok) {
+          if (p.res_mode == SRN_RES_ADD) {
+            v += res[(int64_t)trow * p.ld_res + ocol];
+          } else if (p.res_mode == SRN_RES_AXPY) {
+            v = res[(int64_t)trow * p.ld_res + ocol] + p.beta * v;
+          }
+          if (res2) v += res2[(int64_t)trow * p.ld_res2 + ocol];
+          if (p.post == SRN_POST_DIV) v = v / p.post_div;
+          else if (p.post == SRN_POST_TANH) v = tanhf(v);
+          out[(int64_t)(trow * p.out_t_stride + p.out_t_off) * p.ld_out + ocol] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (p.gn_partials) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const int gmt = (t0 + wm0 + m * 32) >> 5;
+        const int gnt = (n0 + wn0 + n * 32) >> 5;
+        if (lane == 0 && gmt < gn_mt && gnt < gn_nt) {
+          float* gp = p.gn_partials + (((int64_t)zb * gn_mt + gmt) * gn_nt + gnt) * 2;
+          gp[0] = s1;
+          gp[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+struct TileInfo {
+  int id, bm, bn, wn;
+  float base;  // relative efficiency prior of the tile shape
+};
+// id: 1 128x128 (64x64/wave) | 2 128x64 (32x64) | 3 64x128 (32x64) | 4 64x64 (32x32) | 5 128x32 (32x32)
+const TileInfo kTiles[] = {{1, 128, 128, 64, 1.00f}, {2, 128, 64, 64, 0.93f}, {3, 64, 128, 64, 0.93f},
+                           {4, 64, 64, 32, 0.80f},   {5, 128, 32, 32, 0.78f}};
+
+template <class C>
+int launch(const SrnConvParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES));
+    attr_done = true;
+  }
+  const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
+  const int n_tiles = (p.N + C::BN - 1) / C::BN;
+  const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
+  SRN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_gemm: bad grid %lld", (long long)blocks);
+  hipLaunchKernelGGL(conv_gemm_kernel<C>, dim3((unsigned)blocks), dim3(256), C::SMEM_BYTES, stream, p, m_tiles,
+                     n_tiles);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+int pick_tile(const SrnConvParams& p) {
+  float best = -1.f;
+  int best_id = 4;
+  const double z = (double)p.n_batch * p.n_head;
+  for (const TileInfo& t : kTiles) {
+    if (p.geglu && t.wn < 64) continue;
+    if (p.w_nmajor && !(t.id == 1 || t.id == 3 || t.id == 4)) continue;
+    const double mt = (p.T_out + t.bm - 1) / t.bm, nt = (p.N + t.bn - 1) / t.bn;
+    const double blocks = z * mt * nt;
+    const double useful = ((double)p.T_out * p.N) / (mt * t.bm * nt * t.bn);
+    const double rounds = (blocks + 255.0) / 256.0;
+    const double quant = blocks / (256.0 * (double)(int64_t)rounds);
+    const float score = (float)(useful * (quant < 1.0 ? quant : 1.0)) * t.base;
+    if (score > best) {
+      best = score;
+      best_id = t.id;
+    }
+  }
+  return best_id;
+}
+
+}  // namespace
+
+extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
+  SRN_CHECK_ARG(pp != nullptr, "conv_gemm: null params");
+  SrnConvParams p = *pp;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  SRN_CHECK_ARG(p.in0 && p.w && p.out, "conv_gemm: null in0/w/out");
+  SRN_CHECK_ARG(p.n_batch > 0 && p.n_head > 0 && p.T_in > 0 && p.T_out > 0 && p.N > 0, "conv_gemm: bad sizes");
+  SRN_CHECK_ARG(p.C_in > 0 && p.C_in % 4 == 0, "conv_gemm: C_in (%d) must be a positive multiple of 4", p.C_in);
+  SRN_CHECK_ARG(p.n_taps >= 1 && p.n_taps <= SRN_MAX_TAPS, "conv_gemm: n_taps %d out of range", p.n_taps);
+  SRN_CHECK_ARG(p.ld_in0 % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in0) & 15) == 0 && p.in0_bs % 4 == 0 &&
+                    p.in0_hs % 4 == 0,
+                "conv_gemm: in0 must be 16-byte aligned with ld %% 4 == 0");
+  if (p.C_in0 <= 0 || p.C_in0 > p.C_in) p.C_in0 = p.C_in;
+  if (p.C_in0 < p.C_in) {
+    SRN_CHECK_ARG(p.in1 != nullptr && p.C_in0 % 32 == 0 && p.ld_in1 % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.in1) & 15) == 0 && p.in1_bs % 4 == 0,
+                  "conv_gemm: concat input needs in1, C_in0 %% 32 == 0 and aligned in1");
+  }
+  if (p.C_w <= 0 || p.C_w > p.C_in) p.C_w = p.C_in;
+  SRN_CHECK_ARG(p.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0 && p.w_bs % 4 == 0 && p.w_hs % 4 == 0,
+                "conv_gemm: w must be 16-byte aligned with ldw %% 4 == 0");
+  if (p.w_nmajor) {
+    SRN_CHECK_ARG(p.n_taps == 1 && p.N % 4 == 0, "conv_gemm: n-major weights need n_taps == 1 and N %% 4 == 0");
+  } else {
+    SRN_CHECK_ARG(p.C_w % 4 == 0, "conv_gemm: C_w must be a multiple of 4 for k-major weights");
+  }
+  if (p.in_stride <= 0) p.in_stride = 1;
+  if (p.out_t_stride <= 0) p.out_t_stride = 1;
+  if (p.N_out <= 0) p.N_out = p.geglu ? p.N / 2 : p.N;
+  if (p.geglu) SRN_CHECK_ARG(p.N % 64 == 0, "conv_gemm: GEGLU needs N %% 64 == 0");
+  if (p.res_mode != SRN_RES_NONE) SRN_CHECK_ARG(p.res != nullptr, "conv_gemm: res_mode set but res is null");
+  if (p.gn_partials) SRN_CHECK_ARG(p.N % 32 == 0 && !p.geglu, "conv_gemm: gn_partials needs N %% 32 == 0");
+  if (p.pad_reflect) {
+    for (int i = 0; i < p.n_taps; ++i)
+      SRN_CHECK_ARG(p.tap_off[i] > -p.T_in && p.tap_off[i] < p.T_in, "conv_gemm: reflect pad wider than the input");
+  }
+
+  int tile = p.tile > 0 ? p.tile : pick_tile(p);
+  if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
+  if (p.w_nmajor) {
+    switch (tile) {
+      case 1: return launch<Cfg<128, 128, 64, 64, true>>(p, stream);
+      case 3: return launch<Cfg<64, 128, 32, 64, true>>(p, stream);
+      default: return launch<Cfg<64, 64, 32, 32, true>>(p, stream);
+    }
+  }
+  switch (tile) {
+    case 1: return launch<Cfg<128, 128, 64, 64, false>>(p, stream);
+    case 2: return launch<Cfg<128, 64, 32, 64, false>>(p, stream);
+    case 3: return launch<Cfg<64, 128, 32, 64, false>>(p, stream);
+    case 4: return launch<Cfg<64, 64, 32, 32, false>>(p, stream);
+    case 5: return launch<Cfg<128, 32, 32, 32, false>>(p, stream);
+    default: break;
+  }
+  srn_set_error("conv_gemm: unknown tile id %d", tile);
+  return -1;
+}

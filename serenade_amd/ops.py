@@ -1,0 +1,192 @@
+"""Thin Python wrappers over the C ABI (include/serenade_hip.h).
+
+Tensors are torch CUDA fp32 tensors used as device memory only; every wrapper passes raw
+pointers, sizes and the current HIP stream.  All activations are channels-last (B, T, C).
+Nothing here computes on the host and nothing falls back to torch ops or to ``oracle/``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_NONE, POST_TANH, RES_ADD,  # noqa: F401
+                   RES_AXPY, RES_NONE, SrnConvParams, check)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(x):
+    """tensor | (tensor, element_offset) | None -> raw device address (int) or None."""
+    if x is None:
+        return None
+    if isinstance(x, tuple):
+        t, off = x
+        return t.data_ptr() + 4 * int(off)
+    return x.data_ptr()
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32, "expected a CUDA fp32 tensor"
+    return t
+
+
+class ConvOp:
+    """A prebuilt srn_conv_gemm call (parameters frozen, pointers borrowed from live tensors)."""
+
+    __slots__ = ("p", "kw", "_fn")
+
+    def __init__(self, **kw):
+        self.kw = kw  # kept for introspection (tests emulate the C-ABI contract from it) and to pin the tensors
+        self._build(**kw)
+
+    def _build(self, *, in0, w, out, n_batch, T_in, T_out, C_in, N, ld_in0, ldw, ld_out, taps=(0,), n_head=1,
+                 in0_bs=0, in0_hs=0, in1=None, C_in0=0, in1_bs=0, ld_in1=0, C_w=0, w_bs=0, w_hs=0, w_nmajor=False,
+                 bias=None, len_in=None, len_out=None, in_stride=1, reflect=False, pro_act=ACT_NONE, pro_slope=0.0,
+                 alpha=1.0, beta=0.0, geglu=False, res=None, res_mode=RES_NONE, res_bs=0, ld_res=0, res2=None,
+                 res2_bs=0, ld_res2=0, post=POST_NONE, post_div=1.0, out_bs=0, out_hs=0, out_t_stride=1, out_t_off=0,
+                 gn_partials=None, N_out=0, tile=0):
+        p = SrnConvParams()
+        p.n_batch, p.n_head, p.T_in, p.T_out = int(n_batch), int(n_head), int(T_in), int(T_out)
+        p.C_in, p.C_in0, p.C_w, p.N, p.N_out = int(C_in), int(C_in0), int(C_w), int(N), int(N_out)
+        taps = [int(t) for t in taps]
+        assert 1 <= len(taps) <= _lib.SRN_MAX_TAPS
+        p.n_taps = len(taps)
+        for i, t in enumerate(taps):
+            p.tap_off[i] = t
+        p.in_stride, p.pad_reflect, p.w_nmajor = int(in_stride), int(bool(reflect)), int(bool(w_nmajor))
+        p.pro_act, p.pro_slope, p.alpha, p.beta = int(pro_act), float(pro_slope), float(alpha), float(beta)
+        p.geglu, p.res_mode, p.post, p.post_div = int(bool(geglu)), int(res_mode), int(post), float(post_div)
+        p.out_t_stride, p.out_t_off, p.tile = int(out_t_stride), int(out_t_off), int(tile)
+        p.in0, p.in0_bs, p.in0_hs, p.ld_in0 = _ptr(in0), int(in0_bs), int(in0_hs), int(ld_in0)
+        p.in1, p.in1_bs, p.ld_in1 = _ptr(in1), int(in1_bs), int(ld_in1)
+        p.w, p.w_bs, p.w_hs, p.ldw = _ptr(w), int(w_bs), int(w_hs), int(ldw)
+        p.bias, p.len_in, p.len_out = _ptr(bias), _ptr(len_in), _ptr(len_out)
+        p.res, p.res_bs, p.ld_res = _ptr(res), int(res_bs), int(ld_res)
+        p.res2, p.res2_bs, p.ld_res2 = _ptr(res2), int(res2_bs), int(ld_res2)
+        p.out, p.out_bs, p.out_hs, p.ld_out = _ptr(out), int(out_bs), int(out_hs), int(ld_out)
+        p.gn_partials = _ptr(gn_partials)
+        self.p = p
+        self._fn = _lib.lib().srn_conv_gemm
+
+    def __call__(self, stream=None):
+        check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
+
+
+class CallOp:
+    """A prebuilt call of any other C-ABI function (stream appended at run time)."""
+
+    __slots__ = ("_fn", "_args", "targs", "name")
+
+    def __init__(self, name, targs):
+        self._fn = getattr(_lib.lib(), name)
+        self.targs = tuple(targs)  # python-level arguments (tensors / scalars), pins the tensors
+        self._args = tuple(_ptr(a) if (a is None or isinstance(a, (torch.Tensor, tuple))) else a for a in targs)
+        self.name = name
+
+    def __call__(self, stream=None):
+        check(self._fn(*self._args, stream if stream is not None else _stream()), self.name)
+
+
+# ------------------------------------------------------------------ op builders (return CallOp)
+def gn_mish_apply_op(x, partials, gamma, beta, time_bias, lens, y, B, T, C, groups=8, eps=1e-5, tb_bs=0):
+    return CallOp("srn_gn_mish_apply", (x, partials, gamma, beta, time_bias, tb_bs, lens, y, B, T, C, groups, eps))
+
+
+def resblock_tail_op(c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups=8, gn_eps=1e-5,
+                     ln_eps=1e-5):
+    return CallOp("srn_resblock_tail", (c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups,
+                                        gn_eps, ln_eps))
+
+
+def layernorm_op(x, gamma, beta, y, rows, C, eps=1e-5):
+    return CallOp("srn_layernorm", (x, gamma, beta, y, rows, C, eps))
+
+
+def softmax_rows_op(s, lens, Z, n_head, L, ld):
+    return CallOp("srn_softmax_rows", (s, lens, Z, n_head, L, ld))
+
+
+def sinusoidal_emb_op(t, out, n, dim, ld, scale=1000.0):
+    return CallOp("srn_sinusoidal_emb", (t, out, n, dim, ld, scale))
+
+
+def copy_channels_op(src, src_bs, ld_src, sc0, dst, dst_bs, ld_dst, dc0, B, T, C):
+    return CallOp("srn_copy_channels", (src, src_bs, ld_src, sc0, dst, dst_bs, ld_dst, dc0, B, T, C))
+
+
+def transpose_op(src, dst, B, R, Cc, src_bs, ld_src, dst_bs, ld_dst):
+    """dst[b][c][r] = src[b][r][c]"""
+    return CallOp("srn_transpose_ct", (src, dst, B, R, Cc, src_bs, ld_src, dst_bs, ld_dst))
+
+
+def renorm_op(x, trg_scale, trg_mean, voc_mean, voc_scale, y, rows, C):
+    return CallOp("srn_renorm", (x, trg_scale, trg_mean, voc_mean, voc_scale, y, rows, C))
+
+
+def out_conv_tanh_op(x, w, bias, y, B, T, C, k, slope):
+    return CallOp("srn_out_conv_tanh", (x, w, bias, y, B, T, C, k, slope))
+
+
+def conv2d_bn_relu_op(x, w, bn_scale, bn_shift, y, B, H, W, Ci, Co):
+    return CallOp("srn_conv2d_bn_relu", (x, w, bn_scale, bn_shift, y, B, H, W, Ci, Co))
+
+
+def gru_last_op(xs, w_ih, w_hh, b_ih, b_hh, h, B, T, I, H):
+    return CallOp("srn_gru_last", (xs, w_ih, w_hh, b_ih, b_hh, h, B, T, I, H))
+
+
+def style_token_attention_op(ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok, dk_in, F, n_head):
+    return CallOp("srn_style_token_attention", (ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok,
+                                                dk_in, F, n_head))
+
+
+# ------------------------------------------------------------------ weight packing (one-time, at load)
+def pack_conv_weight(w, c_pad=None):
+    """torch Conv1d weight (Co, Ci, k) -> [Co][k][Ci_pad] k-contiguous GEMM operand."""
+    co, ci, k = w.shape
+    cp = ci if c_pad is None else c_pad
+    out = w.new_zeros(co, k, cp)
+    out[:, :, :ci] = w.permute(0, 2, 1)
+    return out.reshape(co, k * cp).contiguous()
+
+
+def conv_taps(k, dilation=1, padding=None):
+    """input-row offsets of a stride-1 Conv1d: tap j reads t + j*dilation - padding."""
+    if padding is None:
+        padding = (k - 1) // 2 * dilation
+    return [j * dilation - padding for j in range(k)]
+
+
+def convtranspose_phases(w, stride, padding):
+    """torch ConvTranspose1d weight (Ci, Co, k) -> per output phase r (out index = m*stride + r):
+    (taps = input-row offsets relative to m, packed weight [Co][n_taps*Ci]).
+    out[o] = sum_i sum_k x[i] w[:, :, k] with o = i*stride - padding + k."""
+    ci, co, k = w.shape
+    phases = []
+    for r in range(stride):
+        taps, mats = [], []
+        # k = r + padding + j*stride for integer j, 0 <= k < kernel;  i = m - j
+        j = -((r + padding) // stride)
+        while True:
+            kk = r + padding + j * stride
+            if kk >= k:
+                break
+            if kk >= 0:
+                taps.append(-j)
+                mats.append(w[:, :, kk].t())  # (Co, Ci)
+            j += 1
+        packed = torch.stack(mats, dim=1).reshape(co, len(taps) * ci).contiguous()
+        phases.append((taps, packed))
+    return phases
+
+
+def pack_geglu(w, b):
+    """GEGLU proj (2*inner, dim): rows [0, inner) = value, [inner, 2 inner) = gate  ->  rows interleaved in
+    32-row (value | gate) groups so one 64-wide MFMA column span holds both halves of 32 outputs."""
+    inner = w.shape[0] // 2
+    assert inner % 32 == 0
+    idx = torch.arange(inner, device=w.device).view(-1, 32)
+    order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+    return w[order].contiguous(), b[order].contiguous()

@@ -1,0 +1,254 @@
+"""TEST-ONLY executable specification of the C ABI (include/serenade_hip.h) in CPU torch.
+
+It lets the CPU test-suite exercise all *host logic* of the product (weight packing, buffer plans,
+strides, tap tables, phase decomposition) without a GPU: ``install()`` swaps the ``__call__`` of
+``ops.ConvOp`` / ``ops.CallOp`` for these functions.  It is never importable from the product and it
+is NOT a fallback: on the GPU box the real library runs and is checked against the oracle.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from serenade_amd import _lib, models, ops, vocoder
+
+
+def _flat(x):
+    if x is None:
+        return None, 0
+    if isinstance(x, tuple):
+        t, off = x
+        return t.view(-1), int(off)
+    return x.view(-1), 0
+
+
+def _act(a, act, slope):
+    if act == _lib.ACT_LEAKY:
+        return F.leaky_relu(a, slope)
+    if act == _lib.ACT_SILU:
+        return F.silu(a)
+    if act == _lib.ACT_MISH:
+        return F.mish(a)
+    return a
+
+
+def emul_conv(kw):
+    g = kw.get
+    nb, nh = g("n_batch"), g("n_head", 1)
+    T_in, T_out, C_in, N = g("T_in"), g("T_out"), g("C_in"), g("N")
+    C_in0 = g("C_in0", 0) or C_in
+    C_w = g("C_w", 0) or C_in
+    taps = list(g("taps", (0,)))
+    in_stride = g("in_stride", 1) or 1
+    geglu = bool(g("geglu", False))
+    N_out = g("N_out", 0) or (N // 2 if geglu else N)
+    in0, o_in0 = _flat(g("in0"))
+    in1, o_in1 = _flat(g("in1"))
+    w, o_w = _flat(g("w"))
+    out, o_out = _flat(g("out"))
+    res, o_res = _flat(g("res"))
+    res2, o_res2 = _flat(g("res2"))
+    gnp, o_gnp = _flat(g("gn_partials"))
+    bias = g("bias")
+    len_in, len_out = g("len_in"), g("len_out")
+    ots, oto = g("out_t_stride", 1) or 1, g("out_t_off", 0)
+    assert C_in % 4 == 0 and g("ld_in0") % 4 == 0 and g("ldw") % 4 == 0
+    assert o_in0 % 4 == 0 and o_w % 4 == 0, "16-byte alignment of in0 / w"
+    t = torch.arange(T_out)
+    for zb in range(nb):
+        li = T_in if len_in is None else min(int(len_in[zb]), T_in)
+        lo = T_out if len_out is None else min(int(len_out[zb]), T_out)
+        for zh in range(nh):
+            A = torch.zeros(T_out, len(taps), C_in)
+            for j, off in enumerate(taps):
+                ti = t * in_stride + off
+                if g("reflect", False):
+                    ti = torch.where(ti < 0, -ti, ti)
+                    ti = torch.where(ti >= T_in, 2 * (T_in - 1) - ti, ti)
+                valid = ((ti >= 0) & (ti < li)).float().unsqueeze(1)
+                tic = ti.clamp(0, T_in - 1)
+                base = o_in0 + zb * g("in0_bs", 0) + zh * g("in0_hs", 0)
+                idx = base + tic.unsqueeze(1) * g("ld_in0") + torch.arange(C_in0).unsqueeze(0)
+                A[:, j, :C_in0] = in0[idx] * valid
+                if C_in0 < C_in:
+                    assert C_in0 % 32 == 0
+                    c1 = C_in - C_in0
+                    idx = o_in1 + zb * g("in1_bs", 0) + tic.unsqueeze(1) * g("ld_in1") + torch.arange(c1).unsqueeze(0)
+                    A[:, j, C_in0:] = in1[idx] * valid
+            A = _act(A, g("pro_act", 0), g("pro_slope", 0.0))
+            wb = o_w + zb * g("w_bs", 0) + zh * g("w_hs", 0)
+            if g("w_nmajor", False):
+                assert len(taps) == 1
+                idx = wb + torch.arange(C_w).unsqueeze(1) * g("ldw") + torch.arange(N).unsqueeze(0)
+                Wm = torch.zeros(C_in, N)
+                Wm[:C_w] = w[idx]
+                val = A.reshape(T_out, -1) @ Wm
+            else:
+                idx = wb + torch.arange(N).unsqueeze(1) * g("ldw") + torch.arange(len(taps) * C_in).unsqueeze(0)
+                Wm = w[idx].reshape(N, len(taps), C_in).clone()
+                Wm[:, :, C_w:] = 0
+                val = A.reshape(T_out, -1) @ Wm.reshape(N, -1).t()
+            val = val * g("alpha", 1.0)
+            if bias is not None:
+                val = val + bias.view(-1)[:N]
+            if geglu:
+                v = val.reshape(T_out, N // 64, 2, 32)
+                val = (v[:, :, 0] * F.gelu(v[:, :, 1])).reshape(T_out, N // 2)
+            val = val[:, :N_out].clone()
+            val[lo:] = 0
+            cols = torch.arange(N_out).unsqueeze(0)
+            if g("res_mode", 0):
+                ridx = o_res + zb * g("res_bs", 0) + t.unsqueeze(1) * g("ld_res") + cols
+                if g("res_mode") == _lib.RES_ADD:
+                    val = val + res[ridx]
+                else:
+                    val = res[ridx] + g("beta", 0.0) * val
+            if res2 is not None:
+                val = val + res2[o_res2 + zb * g("res2_bs", 0) + t.unsqueeze(1) * g("ld_res2") + cols]
+            if g("post", 0) == _lib.POST_DIV:
+                val = val / g("post_div", 1.0)
+            elif g("post", 0) == _lib.POST_TANH:
+                val = torch.tanh(val)
+            oidx = o_out + zb * g("out_bs", 0) + zh * g("out_hs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_out") + cols
+            out[oidx] = val
+            if gnp is not None:
+                mt, nt = (T_out + 31) // 32, N // 32
+                pad = torch.zeros(mt * 32, nt * 32)
+                pad[:T_out, :N_out] = val
+                tiles = pad.reshape(mt, 32, nt, 32)
+                part = torch.stack([tiles.sum(dim=(1, 3)), (tiles ** 2).sum(dim=(1, 3))], dim=-1)
+                gnp[o_gnp + zb * mt * nt * 2: o_gnp + (zb + 1) * mt * nt * 2] = part.reshape(-1)
+
+
+def _v(x, n=None):
+    """flat view of a tensor or (tensor, offset), optionally the first n elements"""
+    f, o = _flat(x)
+    return f[o:] if n is None else f[o:o + n]
+
+
+def _group_stats(partials, b, T, C, groups, eps):
+    mt, nt = (T + 31) // 32, C // 32
+    p = _v(partials)[b * mt * nt * 2:(b + 1) * mt * nt * 2].reshape(mt, nt, 2).double()
+    per = (C // groups) // 32
+    s = p.reshape(mt, groups, per, 2).sum(dim=(0, 2))
+    cnt = T * (C // groups)
+    mean = s[:, 0] / cnt
+    var = (s[:, 1] / cnt - mean * mean).clamp_min(0)
+    return mean.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+
+def emul_call(name, a):
+    if name == "srn_gn_mish_apply":
+        x, part, gamma, beta, tb, tb_bs, lens, y, B, T, C, groups, eps = a
+        xv, yv = _v(x, B * T * C).reshape(B, T, C), _v(y, B * T * C).reshape(B, T, C)
+        for b in range(B):
+            mean, rstd = _group_stats(part, b, T, C, groups, eps)
+            m = mean.repeat_interleave(C // groups)
+            r = rstd.repeat_interleave(C // groups)
+            o = F.mish((xv[b] - m) * r * gamma + beta)
+            if tb is not None:
+                o = o + _v(tb)[b * tb_bs: b * tb_bs + C]
+            ln = T if lens is None else min(int(lens[b]), T)
+            o[ln:] = 0
+            yv[b] = o
+    elif name == "srn_resblock_tail":
+        c2, part, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups, ge, le = a
+        xv, rv, yv = (_v(t, B * T * C).reshape(B, T, C) for t in (c2, r, y))
+        for b in range(B):
+            mean, rstd = _group_stats(part, b, T, C, groups, ge)
+            m = mean.repeat_interleave(C // groups)
+            rs = rstd.repeat_interleave(C // groups)
+            o = F.mish((xv[b] - m) * rs * gamma + beta)
+            ln = T if lens is None else min(int(lens[b]), T)
+            o[ln:] = 0
+            v = o + rv[b]
+            mu = v.mean(dim=-1, keepdim=True)
+            var = ((v - mu) ** 2).mean(dim=-1, keepdim=True)
+            yv[b] = (v - mu) / (var + le).sqrt() * _v(scale)[b * ld_ss: b * ld_ss + C] + _v(shift)[b * ld_ss: b * ld_ss + C]
+    elif name == "srn_layernorm":
+        x, gamma, beta, y, rows, C, eps = a
+        _v(y, rows * C).reshape(rows, C)[:] = F.layer_norm(_v(x, rows * C).reshape(rows, C), (C,), gamma, beta, eps)
+    elif name == "srn_softmax_rows":
+        s, lens, Z, nh, L, ld = a
+        sv = _v(s, Z * L * ld).reshape(Z, L, ld)
+        for z in range(Z):
+            ln = L if lens is None else min(int(lens[z // nh]), L)
+            row = sv[z, :, :L].clone()
+            row[:, ln:] = float("-inf")
+            sv[z, :, :L] = torch.softmax(row, dim=-1)
+            sv[z, :, L:] = 0
+    elif name == "srn_sinusoidal_emb":
+        t, out, n, dim, ld, scale = a
+        half = dim // 2
+        e = math.log(10000) / (half - 1)
+        f = torch.exp(torch.arange(half).float() * -e)
+        arg = scale * _v(t, n).unsqueeze(1) * f.unsqueeze(0)
+        ov = _v(out, n * ld).reshape(n, ld)
+        ov[:, :half] = arg.sin()
+        ov[:, half:dim] = arg.cos()
+    elif name == "srn_copy_channels":
+        src, sbs, lds, sc0, dst, dbs, ldd, dc0, B, T, C = a
+        sf, df = _v(src), _v(dst)
+        tt, cc = torch.arange(T).unsqueeze(1), torch.arange(C).unsqueeze(0)
+        for b in range(B):
+            df[b * dbs + tt * ldd + dc0 + cc] = sf[b * sbs + tt * lds + sc0 + cc]
+    elif name == "srn_transpose_ct":
+        src, dst, B, R, Cc, sbs, lds, dbs, ldd = a
+        sf, df = _v(src), _v(dst)
+        rr, cc = torch.arange(R).unsqueeze(1), torch.arange(Cc).unsqueeze(0)
+        for b in range(B):
+            df[b * dbs + cc * ldd + rr] = sf[b * sbs + rr * lds + cc]
+    elif name == "srn_renorm":
+        x, ts, tm, vm, vs, y, rows, C = a
+        v = _v(x, rows * C).reshape(rows, C)
+        if ts is not None:
+            v = v * ts + tm
+        _v(y, rows * C).reshape(rows, C)[:] = (v - vm) / vs
+    elif name == "srn_out_conv_tanh":
+        x, w, bias, y, B, T, C, k, slope = a
+        xv = F.leaky_relu(_v(x, B * T * C).reshape(B, T, C), slope).transpose(1, 2)
+        wv = _v(w, k * C).reshape(k, C).t().unsqueeze(0)
+        _v(y, B * T).reshape(B, T)[:] = torch.tanh(F.conv1d(xv, wv, bias.view(-1), padding=(k - 1) // 2))[:, 0]
+    elif name == "srn_conv2d_bn_relu":
+        x, w, sc, sh, y, B, H, W, Ci, Co = a
+        xv = _v(x, B * H * W * Ci).reshape(B, H, W, Ci).permute(0, 3, 1, 2)
+        o = F.conv2d(xv, w.permute(0, 3, 1, 2), None, stride=2, padding=1)
+        o = F.relu(o * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        _v(y, o.numel()).reshape(o.shape)[:] = o
+    elif name == "srn_gru_last":
+        xs, wih, whh, bih, bhh, h, B, T, I, H = a
+        xv = _v(xs, B * T * I).reshape(B, T, I)
+        hh = torch.zeros(B, H)
+        for t in range(T):
+            gi, gh = xv[:, t] @ wih.t() + bih, hh @ whh.t() + bhh
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            hh = (1 - z) * n + z * hh
+        _v(h, B * H).reshape(B, H)[:] = hh
+    elif name == "srn_style_token_attention":
+        ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok, dk_in, Fd, nh = a
+        toks = torch.tanh(embs)
+        q = _v(ref, B * Dq).reshape(B, Dq) @ wq.t() + bq
+        k, v = toks @ wk.t() + bk, toks @ wv.t() + bv
+        dk = Fd // nh
+        sc = torch.einsum("bhd,thd->bht", q.view(B, nh, dk), k.view(n_tok, nh, dk)) / math.sqrt(dk)
+        ctx = torch.einsum("bht,thd->bhd", torch.softmax(sc, -1), v.view(n_tok, nh, dk)).reshape(B, Fd)
+        _v(out, B * Fd).reshape(B, Fd)[:] = ctx @ wo.t() + bo
+    else:
+        raise NotImplementedError(name)
+
+
+class installed:
+    """context manager: route every op through the emulator and lift the CUDA-only guard"""
+
+    def __enter__(self):
+        self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, models._require_cuda, vocoder._require_cuda)
+        ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)
+        ops.CallOp.__call__ = lambda self_, stream=None: emul_call(self_.name, self_.targs)
+        models._require_cuda = lambda *a, **k: None
+        vocoder._require_cuda = lambda *a, **k: None
+        return self
+
+    def __exit__(self, *exc):
+        ops.ConvOp.__call__, ops.CallOp.__call__, models._require_cuda, vocoder._require_cuda = self._saved
