@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: converted source mel frames / second of the Serenade audio-infilling inference path
+(GST style encoder -> content encoder -> 1-D UNet flow-matching Euler ODE -> HiFi-GAN vocoder) on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch per GPU: `Serenade.inference` (B=8 utterances of
+T=1024 source frames with a 256-frame prompt, 10 Euler steps) + `Vocoder.decode_batch`, inputs already resident
+in HBM; with N > 1 every rank converts its own batch (utterances shard embarrassingly, weak scaling) and the
+converted waveforms are gathered on rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, T_SRC, T_REF, N_EULER = 8, 1024, 256, 10
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def algorithmic_flops(B, T, T_ref, n):
+    """SURVEY.md section 8(d) per-utterance work: estimator 81.3e6*L + 24576*L^2 per call, encoder 11.32e6 per
+    frame, HiFi-GAN 499e6 per source frame (all of it runs in the conv_gemm kernel; GST's 0.8 GFLOP does not)."""
+    L = T + T_ref
+    return B * (n * (81.3e6 * L + 24576.0 * L * L) + 11.32e6 * (T + T_ref) + 499e6 * T)
+
+
+def build_models(dev):
+    from serenade_amd import _shapes, models, vocoder
+    from serenade_amd.utils.synth import HIFIGAN_PARAMS, SERENADE_PARAMS, fill_state_dict
+    sd = fill_state_dict(_shapes.as_meta(_shapes.serenade_shapes(**SERENADE_PARAMS)), seed=0)
+    model = models.Serenade(**SERENADE_PARAMS)
+    model.load_state_dict(sd)
+    model = model.eval().to(dev)
+    gsd = fill_state_dict(_shapes.as_meta(_shapes.hifigan_shapes(**HIFIGAN_PARAMS, weight_norm=True)), seed=0)
+    gen = vocoder.HiFiGANGenerator(**HIFIGAN_PARAMS)
+    gen.load_state_dict(gsd)
+    one = np.ones(80, dtype=np.float32)
+    ident = {"mean": 0 * one, "scale": one}
+    voc = vocoder.Vocoder.from_generator(gen, {"sampling_rate": 24000}, ident, dev, trg_stats=ident)
+    return model, voc, sd, gsd
+
+
+def cpu_baseline(sd, gsd):
+    """The CPU oracle (a port of the reference's CPU path, pinned to its golden vectors) timed on this box's
+    host cores on a bounded sample: ONE utterance of the same workload."""
+    from oracle import serenade_oracle as O
+    from serenade_amd.utils.synth import HIFIGAN_PARAMS, synth_inputs
+    d = synth_inputs(1, T_SRC, T_ref=T_REF, seed=1235)
+    threads = torch.get_num_threads()
+    t1 = torch.ones(80)
+    ident = {"mean": 0 * t1, "scale": t1}
+    with torch.no_grad():
+        t0 = time.time()
+        mel = O.serenade_inference(sd, d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
+                                   d["ref_logmel"], d["ref_midi"], d["ref_lft"], d["z"], n_timesteps=N_EULER)
+        O.vocoder_decode(gsd, mel, HIFIGAN_PARAMS, ident, ident)
+        dt = time.time() - t0
+    return {"value": T_SRC / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 utterance of the workload (T={T_SRC}, T_ref={T_REF}, {N_EULER} Euler steps + HiFi-GAN), "
+                      f"fp32 torch CPU, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from serenade_amd import ops
+    from serenade_amd.parallel import gather_waveforms
+    from serenade_amd.utils.synth import synth_inputs
+
+    model, voc, sd, gsd = build_models(dev)
+    d = synth_inputs(B_PER_GPU, T_SRC, T_ref=T_REF, seed=1235 + rank)
+    g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
+
+    def step():
+        mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"],
+                              g["ref_logmel"], g["ref_midi"], g["ref_lft"], n_timesteps=N_EULER, noise=g["z"])
+        wave = voc.decode_batch(mel)
+        return gather_waveforms(wave, dst=0) if world > 1 else wave
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = world * B_PER_GPU * T_SRC * args.steps
+    value = frames / elapsed
+    # dominant kernel: conv_gemm (all instantiations); HIP events recorded on the launch stream in the timed region
+    durs = np.array([s.elapsed_time(e) for s, e in prof], dtype=np.float64)  # ms
+    n_launch = len(durs) / max(args.steps, 1)
+    gemm_ms_per_step = durs.sum() / max(args.steps, 1)
+    fl = algorithmic_flops(B_PER_GPU, T_SRC, T_REF, N_EULER)
+    achieved = fl / (gemm_ms_per_step * 1e-3) / 1e12 if gemm_ms_per_step > 0 else 0.0
+    out = {
+        "metric": "mel frames/sec converted (UNet ODE + vocoder), 80x1024",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"B={B_PER_GPU}/GPU x T={T_SRC} source frames (80-dim mel), T_ref={T_REF} prompt, "
+                               f"{N_EULER} Euler steps, UNet ODE + HiFi-GAN (8,5,3,2) on GPU; waveform gather to "
+                               f"rank 0 when N>1", "global_batch": world * B_PER_GPU, "x_realtime": value / 100.0},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM, all tile instantiations)",
+                     "launches_per_step": n_launch, "avg_launch_us": (durs.mean() * 1e3) if len(durs) else 0.0,
+                     "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
+                     "kernel_time_share": gemm_ms_per_step / (elapsed / args.steps * 1e3)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd, gsd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,9 @@ from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_NONE,
                    RES_AXPY, RES_NONE, SrnConvParams, check)
 
 
+PROFILE = None  # set to a list by bench.py to collect (start, end) HIP events per conv_gemm launch
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -71,6 +74,14 @@ class ConvOp:
         self._fn = _lib.lib().srn_conv_gemm
 
     def __call__(self, stream=None):
+        if PROFILE is not None and stream is None:
+            # bench.py: HIP events on the launch stream around every conv_gemm launch
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            check(self._fn(ctypes.byref(self.p), _stream()), "srn_conv_gemm")
+            e.record()
+            PROFILE.append((s, e))
+            return
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
 
 

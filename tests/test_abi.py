@@ -1,0 +1,60 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports every symbol include/serenade_hip.h declares,
+and the ctypes mirror of SrnConvParams has the C layout (checked with a gcc-compiled probe)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from serenade_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "serenade_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(srn_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)  # no-op when up to date; hipcc cross-compiles without a GPU
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in serenade_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_error_reporting_without_gpu(lib):
+    assert lib.srn_abi_version() == 1
+    assert lib.srn_conv_gemm(None, None) == -1
+    assert b"null params" in lib.srn_last_error()
+    p = _lib.SrnConvParams()
+    assert lib.srn_conv_gemm(ctypes.byref(p), None) == -1  # argument validation happens before any launch
+    assert b"null in0" in lib.srn_last_error()
+
+
+def test_struct_layout_matches_c(tmp_path):
+    fields = [f[0] for f in _lib.SrnConvParams._fields_]
+    probe = tmp_path / "probe.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){',
+             'printf("%zu\\n", sizeof(SrnConvParams));']
+    for f in fields:
+        lines.append(f'printf("%zu\\n", offsetof(SrnConvParams, {f}));')
+    lines.append("return 0;}")
+    probe.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-o", str(exe), str(probe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_lib.SrnConvParams)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_lib.SrnConvParams, f).offset == off, f

@@ -1,0 +1,69 @@
+"""world_size-2 gloo test (CPU) of the only multi-GPU step of the path: utterance sharding + waveform gather."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from serenade_amd.parallel import gather_waveforms, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 5  # 5 utterances over 2 ranks -> 3 + 2 (ragged), different lengths per rank
+    a, b = shard_range(total, rank, world)
+    n = 480 + 240 * rank
+    wave = torch.stack([torch.full((n,), float(i)) + torch.arange(n) * 1e-3 for i in range(a, b)])
+    lens = torch.tensor([n - 10 * i for i in range(a, b)], dtype=torch.int64)
+    out = gather_waveforms(wave, lens, dst=0)
+    if rank == 0:
+        waves, ns = out
+        q.put(([w.clone() for w in waves], [x.clone() for x in ns]))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_waveforms_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    waves, ns = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [tuple(w.shape) for w in waves] == [(3, 480), (2, 720)]
+    assert ns[0].tolist() == [480, 470, 460] and ns[1].tolist() == [690, 680]
+    assert waves[1][0, 0].item() == 3.0 and abs(waves[1][1, 719].item() - (4.0 + 0.719)) < 1e-5
+
+
+def test_single_process_is_identity():
+    w = torch.randn(2, 10)
+    waves, ns = gather_waveforms(w)
+    assert waves[0] is w and ns[0].tolist() == [10, 10]
