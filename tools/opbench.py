@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-op timing of the headline workload's plan (developer tool, GPU only): times every distinct conv_gemm call of
+one Euler step + the vocoder and prints achieved TFLOP/s per shape, sorted by time share.
+
+    python tools/opbench.py [tile-override]
+"""
+import collections
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from serenade_amd import ops  # noqa: E402
+
+
+def sig(k):
+    return (k["n_batch"] * k.get("n_head", 1), k["T_out"], k["N"], len(k.get("taps", (0,))) * k["C_in"],
+            len(k.get("taps", (0,))), bool(k.get("w_nmajor", False)), bool(k.get("geglu", False)),
+            k.get("in_stride", 1), bool(k.get("gn_partials") is not None), k.get("pro_act", 0))
+
+
+def time_ops(oplist, reps=5):
+    agg = collections.OrderedDict()
+    for op in oplist:
+        if not isinstance(op, ops.ConvOp):
+            continue
+        op()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            op()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        a = agg.setdefault(sig(op.kw), [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    return agg
+
+
+def report(title, agg):
+    tot = sum(v[1] for v in agg.values())
+    print(f"== {title}: {tot:.2f} ms total")
+    print(f"{'Z':>4} {'T_out':>7} {'N':>5} {'K':>6} taps nmaj geglu str gn act | cnt  ms_each   TF/s  share")
+    for k, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        Z, T, N, K, taps, nmaj, geglu, st, gn, act = k
+        fl = 2.0 * Z * T * N * K
+        print(f"{Z:4d} {T:7d} {N:5d} {K:6d} {taps:4d} {int(nmaj):4d} {int(geglu):5d} {st:3d} {int(gn):2d} {act:3d} | "
+              f"{cnt:3d} {ms / cnt:8.3f} {fl * cnt / (ms * 1e-3) / 1e12:6.1f} {ms / tot * 100:6.1f}%")
+
+
+def main():
+    dev = torch.device("cuda:0")
+    model, voc, sd, gsd = bench.build_models(dev)
+    B, T, Tr = bench.B_PER_GPU, bench.T_SRC, bench.T_REF
+    from serenade_amd.utils.synth import synth_inputs
+    d = synth_inputs(B, T, T_ref=Tr, seed=1235)
+    g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
+    mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"], g["ref_logmel"],
+                          g["ref_midi"], g["ref_lft"], noise=g["z"])
+    voc.decode_batch(mel)
+    torch.cuda.synchronize()
+    pl = model.cfm_decoder.estimator.plan(B, T + Tr, 10, euler=True)
+    report("one Euler step (x10 per utterance batch)", time_ops(pl.steps[0]))
+    vp = voc.model.plan(B, T)
+    report("HiFi-GAN forward", time_ops(vp.ops))
+
+
+if __name__ == "__main__":
+    main()
