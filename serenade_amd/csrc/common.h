@@ -32,10 +32,10 @@ void srn_set_error(const char* fmt, ...);
 // n = e^x (e^x + 2): one exp, one divide, no cancellation for very negative x; softplus
 // threshold 20 as in torch (x > 20 -> x).
 __device__ __forceinline__ float srn_mish(float x) {
-  if (x > 20.0f) return x;
-  const float e = expf(x);
+  const float e = expf(fminf(x, 20.0f));
   const float n = e * (e + 2.0f);
-  return x * (n / (n + 2.0f));
+  const float y = x * (n / (n + 2.0f));
+  return x > 20.0f ? x : y;  // branch-free select
 }
 
 __device__ __forceinline__ float srn_silu(float x) { return x / (1.0f + expf(-x)); }

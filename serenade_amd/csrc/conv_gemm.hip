@@ -48,8 +48,15 @@ __device__ __forceinline__ float4 act4(float4 v, int act, float slope) {
   return v;
 }
 
-template <class C>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const SrnConvParams p, const int m_tiles,
+// component-wise select (a float4 ?: is lowered through scratch memory by hipcc)
+__device__ __forceinline__ float4 sel4(unsigned ok, const float4& v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// ACT: prologue activation compiled in: SRN_ACT_NONE, SRN_ACT_LEAKY, or -1 = decided at run time (SiLU / Mish:
+// only the tiny time-embedding GEMMs use those, so only the small tile is instantiated with -1).
+template <class C, int ACT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p, const int m_tiles,
                                                         const int n_tiles) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -98,23 +105,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SrnConvParams p, c
 
   float4 pa[C::A_LD];
   float4 pb[C::B_LD];
+  unsigned a_ok = 0, b_ok = 0;  // validity bits of the tile rows staged in pa / pb
 
+  // Issue-only: every load targets an in-bounds (clamped) address and nothing here consumes a loaded value, so
+  // no s_waitcnt is needed until store_step() -- the loads stay in flight under the MFMA phase.
   auto load_step = [&](int step) {
     const int tap = step / n_chunks;
     const int chunk = step - tap * n_chunks;
     const int ch = chunk * BK + c4 * 4;
     const int toff = p.tap_off[tap];
-    // A: gathered, masked, activated input rows
     {
       const float* src = in0;
       int ld = p.ld_in0;
       int c = ch;
-      if (ch >= p.C_in0) {
+      const bool cok = ch < p.C_in;
+      if (cok && ch >= p.C_in0) {
         src = in1;
         ld = p.ld_in1;
         c = ch - p.C_in0;
       }
-      const bool cok = ch < p.C_in;
+      if (!cok) c = 0;
+      a_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::A_LD; ++i) {
         int ti = a_tb[i] + toff;
@@ -122,56 +133,72 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SrnConvParams p, c
           if (ti < 0 && ti > -(1 << 28)) ti = -ti;
           if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
         }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && ti >= 0 && ti < len_in) {
-          v = *reinterpret_cast<const float4*>(src + (int64_t)ti * ld + c);
-          v = act4(v, p.pro_act, p.pro_slope);
-        }
-        pa[i] = v;
+        const bool ok = cok && ti >= 0 && ti < len_in;
+        a_ok |= (ok ? 1u : 0u) << i;
+        ti = min(max(ti, 0), T_in - 1);
+        pa[i] = *reinterpret_cast<const float4*>(src + (int64_t)ti * ld + c);
       }
     }
-    // B: weights
     if constexpr (!C::NMAJ) {
       const bool kok = ch < p.C_w;
-      const int64_t kcol = (int64_t)tap * p.C_in + ch;
+      const int64_t kcol = (int64_t)tap * p.C_in + (kok ? ch : 0);
+      b_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kok && n < p.N) v = *reinterpret_cast<const float4*>(wgt + (int64_t)n * p.ldw + kcol);
-        pb[i] = v;
+        int n = n0 + lrow + 32 * i;
+        const bool ok = kok && n < p.N;
+        b_ok |= (ok ? 1u : 0u) << i;
+        n = min(n, p.N - 1);
+        pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)n * p.ldw + kcol);
       }
     } else {
       constexpr int F4_PER_ROW = BN / 4;
+      b_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         const int f = tid + i * 256;
         const int krow = f / F4_PER_ROW;
-        const int n = n0 + (f % F4_PER_ROW) * 4;
-        const int k = chunk * BK + krow;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < p.C_w && n < p.N) v = *reinterpret_cast<const float4*>(wgt + (int64_t)k * p.ldw + n);
-        pb[i] = v;
+        int n = n0 + (f % F4_PER_ROW) * 4;
+        int k = chunk * BK + krow;
+        const bool ok = k < p.C_w && n < p.N;
+        b_ok |= (ok ? 1u : 0u) << i;
+        k = min(k, p.C_w - 1);
+        n = min(n, p.N - 4);
+        pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)k * p.ldw + n);
       }
     }
   };
 
+  const int pro_act = p.pro_act;
+  const float pro_slope = p.pro_slope;
   auto store_step = [&](int stage) {
     float* a = As + stage * C::A_STAGE;
     float* b = Bs + stage * C::B_STAGE;
 #pragma unroll
-    for (int i = 0; i < C::A_LD; ++i)
-      *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDK + c4 * 4) = pa[i];
+    for (int i = 0; i < C::A_LD; ++i) {
+      float4 v = sel4((a_ok >> i) & 1u, pa[i]);
+      // act(0) == 0 for every supported activation, so masked rows stay zero
+      if constexpr (ACT == SRN_ACT_LEAKY) {
+        v.x = v.x > 0.f ? v.x : v.x * pro_slope;
+        v.y = v.y > 0.f ? v.y : v.y * pro_slope;
+        v.z = v.z > 0.f ? v.z : v.z * pro_slope;
+        v.w = v.w > 0.f ? v.w : v.w * pro_slope;
+      } else if constexpr (ACT < 0) {
+        v = act4(v, pro_act, pro_slope);
+      }
+      *reinterpret_cast<float4*>(a + (lrow + 32 * i) * LDK + c4 * 4) = v;
+    }
     if constexpr (!C::NMAJ) {
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i)
-        *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDK + c4 * 4) = pb[i];
+        *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDK + c4 * 4) = sel4((b_ok >> i) & 1u, pb[i]);
     } else {
       constexpr int F4_PER_ROW = BN / 4;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         const int f = tid + i * 256;
-        *reinterpret_cast<float4*>(b + (f / F4_PER_ROW) * C::LDN + (f % F4_PER_ROW) * 4) = pb[i];
+        *reinterpret_cast<float4*>(b + (f / F4_PER_ROW) * C::LDN + (f % F4_PER_ROW) * 4) =
+            sel4((b_ok >> i) & 1u, pb[i]);
       }
     }
   };
@@ -216,15 +243,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SrnConvParams p, c
           bf[n] = make_float4(bp[0], bp[C::LDN], bp[2 * C::LDN], bp[3 * C::LDN]);
         }
       }
+      // k-step outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
-        }
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
     }
     if (step + 1 < n_steps) store_step(cur ^ 1);
     __syncthreads();
@@ -309,11 +344,11 @@ struct TileInfo {
 const TileInfo kTiles[] = {{1, 128, 128, 64, 1.00f}, {2, 128, 64, 64, 0.93f}, {3, 64, 128, 64, 0.93f},
                            {4, 64, 64, 32, 0.80f},   {5, 128, 32, 32, 0.78f}};
 
-template <class C>
-int launch(const SrnConvParams& p, hipStream_t stream) {
+template <class C, int ACT>
+int launch_act(const SrnConvParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C>),
+    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C, ACT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES));
     attr_done = true;
   }
@@ -321,10 +356,18 @@ int launch(const SrnConvParams& p, hipStream_t stream) {
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
   SRN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_gemm: bad grid %lld", (long long)blocks);
-  hipLaunchKernelGGL(conv_gemm_kernel<C>, dim3((unsigned)blocks), dim3(256), C::SMEM_BYTES, stream, p, m_tiles,
+  hipLaunchKernelGGL((conv_gemm_kernel<C, ACT>), dim3((unsigned)blocks), dim3(256), C::SMEM_BYTES, stream, p, m_tiles,
                      n_tiles);
   SRN_CHECK_LAUNCH();
   return 0;
+}
+
+template <class C>
+int launch(const SrnConvParams& p, hipStream_t stream) {
+  if (p.pro_act == SRN_ACT_NONE) return launch_act<C, SRN_ACT_NONE>(p, stream);
+  if (p.pro_act == SRN_ACT_LEAKY) return launch_act<C, SRN_ACT_LEAKY>(p, stream);
+  // SiLU / Mish prologue: run-time activation, small tile only
+  return launch_act<Cfg<64, 64, 32, 32, C::NMAJ>, -1>(p, stream);
 }
 
 int pick_tile(const SrnConvParams& p) {
