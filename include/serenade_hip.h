@@ -32,6 +32,8 @@ enum { SRN_ACT_NONE = 0, SRN_ACT_LEAKY = 1, SRN_ACT_SILU = 2, SRN_ACT_MISH = 3 }
 /* residual mode */
 enum { SRN_RES_NONE = 0, SRN_RES_ADD = 1, SRN_RES_AXPY = 2 };
 /* post op */
+/* arithmetic of the contraction */
+enum { SRN_PREC_FP32 = 0 /* exact fp32 MFMA */, SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */ };
 enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2 };
 
 /*
@@ -85,6 +87,7 @@ typedef struct SrnConvParams {
   const float* res;  int64_t res_bs; int32_t ld_res;
   const float* res2; int64_t res2_bs; int32_t ld_res2;  /* second additive residual (HiFi-GAN stage sum) */
   float* out; int64_t out_bs, out_hs; int32_t ld_out;
+  int32_t precision;  /* SRN_PREC_* */
   float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */
 } SrnConvParams;
 

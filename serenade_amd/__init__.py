@@ -1,0 +1,28 @@
+"""serenade_amd — MI355X-native inference hot path of imulki/serenade.
+
+Contraction arithmetic policy (applies to plans built afterwards):
+
+    serenade_amd.set_precision("bf16x3")   # default: every fp32 operand split into (hi, lo) bf16, 3 MFMA per
+                                           # product, fp32 accumulate (~2^-17 relative per product)
+    serenade_amd.set_precision("fp32")     # exact fp32 MFMA (bit-for-bit an fp32 fma chain)
+
+or the environment variable SERENADE_AMD_PRECISION=fp32|bf16x3.
+"""
+import os
+
+from . import _lib, ops
+
+_NAMES = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}
+
+
+def set_precision(name):
+    if name not in _NAMES:
+        raise ValueError(f"precision must be one of {sorted(_NAMES)}, got {name!r}")
+    ops.DEFAULT_PRECISION = _NAMES[name]
+
+
+def get_precision():
+    return {v: k for k, v in _NAMES.items()}[ops.DEFAULT_PRECISION]
+
+
+set_precision(os.environ.get("SERENADE_AMD_PRECISION", "bf16x3"))

@@ -14,6 +14,7 @@ SRN_MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_AXPY = 0, 1, 2
 POST_NONE, POST_DIV, POST_TANH = 0, 1, 2
+PREC_FP32, PREC_BF16X3 = 0, 1
 
 
 class SrnConvParams(ctypes.Structure):
@@ -31,7 +32,7 @@ class SrnConvParams(ctypes.Structure):
         ("res", c_void_p), ("res_bs", c_int64), ("ld_res", c_int32),
         ("res2", c_void_p), ("res2_bs", c_int64), ("ld_res2", c_int32),
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ld_out", c_int32),
-        ("gn_partials", c_void_p),
+        ("precision", c_int32), ("gn_partials", c_void_p),
     ]
 
 

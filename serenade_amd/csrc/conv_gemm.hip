@@ -17,6 +17,8 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -53,15 +55,40 @@ __device__ __forceinline__ float4 sel4(unsigned ok, const float4& v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to 2^-17 relative (round-to-nearest twice; hipcc emits
+// v_cvt_pk_bf16_f32 + shift/and + v_sub: 3 VALU ops per element)
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x;
+  hi[1] = (__bf16)v.y;
+  hi[2] = (__bf16)v.z;
+  hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// byte offset of bf16 element (row, k) in a [rows][32] bf16 tile with 64-B rows whose four 16-B chunks are
+// XOR-swizzled by (row >> 2) & 3: ds_read_b128 of 16 different rows at one logical chunk is conflict-free
+__device__ __forceinline__ int bf_off(int row, int k) {
+  return row * 64 + ((((k >> 3) ^ (row >> 2)) & 3) << 4) + ((k & 7) << 1);
+}
+
 // ACT: prologue activation compiled in: SRN_ACT_NONE, SRN_ACT_LEAKY, or -1 = decided at run time (SiLU / Mish:
 // only the tiny time-embedding GEMMs use those, so only the small tile is instantiated with -1).
-template <class C, int ACT>
+// PREC: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-bf16: every fp32 operand is staged in LDS as a
+// (hi, lo) bf16 pair and each product is three v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi), fp32 accumulate:
+// ~2^-17 relative error per product at 16/3 x the fp32 MFMA rate.
+template <class C, int ACT, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p, const int m_tiles,
                                                         const int n_tiles) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * C::A_STAGE;
+  // split-bf16 stage: [A_hi | A_lo | B_hi | B_lo], 64 B per tile row
+  constexpr int BF_STAGE = (BM + BN) * 128;
+  unsigned char* smem_b = reinterpret_cast<unsigned char*>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,13 +130,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
     a_tb[i] = (t < p.T_out) ? t * p.in_stride : -(1 << 29);
   }
 
-  float4 pa[C::A_LD];
-  float4 pb[C::B_LD];
-  unsigned a_ok = 0, b_ok = 0;  // validity bits of the tile rows staged in pa / pb
+  // register staging set of the tile in flight
+  struct Regs {
+    float4 pa[C::A_LD];
+    float4 pb[C::B_LD];
+    unsigned a_ok, b_ok;  // validity bits of the tile rows staged in pa / pb
+  };
+  Regs R0;
 
   // Issue-only: every load targets an in-bounds (clamped) address and nothing here consumes a loaded value, so
   // no s_waitcnt is needed until store_step() -- the loads stay in flight under the MFMA phase.
-  auto load_step = [&](int step) {
+  auto load_step = [&](int step, Regs& R) {
     const int tap = step / n_chunks;
     const int chunk = step - tap * n_chunks;
     const int ch = chunk * BK + c4 * 4;
@@ -125,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
         c = ch - p.C_in0;
       }
       if (!cok) c = 0;
-      a_ok = 0;
+      R.a_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::A_LD; ++i) {
         int ti = a_tb[i] + toff;
@@ -134,26 +165,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
           if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
         }
         const bool ok = cok && ti >= 0 && ti < len_in;
-        a_ok |= (ok ? 1u : 0u) << i;
+        R.a_ok |= (ok ? 1u : 0u) << i;
         ti = min(max(ti, 0), T_in - 1);
-        pa[i] = *reinterpret_cast<const float4*>(src + (int64_t)ti * ld + c);
+        R.pa[i] = *reinterpret_cast<const float4*>(src + (int64_t)ti * ld + c);
       }
     }
     if constexpr (!C::NMAJ) {
       const bool kok = ch < p.C_w;
       const int64_t kcol = (int64_t)tap * p.C_in + (kok ? ch : 0);
-      b_ok = 0;
+      R.b_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         int n = n0 + lrow + 32 * i;
         const bool ok = kok && n < p.N;
-        b_ok |= (ok ? 1u : 0u) << i;
+        R.b_ok |= (ok ? 1u : 0u) << i;
         n = min(n, p.N - 1);
-        pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)n * p.ldw + kcol);
+        R.pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)n * p.ldw + kcol);
       }
     } else {
       constexpr int F4_PER_ROW = BN / 4;
-      b_ok = 0;
+      R.b_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         const int f = tid + i * 256;
@@ -161,22 +192,73 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
         int n = n0 + (f % F4_PER_ROW) * 4;
         int k = chunk * BK + krow;
         const bool ok = k < p.C_w && n < p.N;
-        b_ok |= (ok ? 1u : 0u) << i;
+        R.b_ok |= (ok ? 1u : 0u) << i;
         k = min(k, p.C_w - 1);
         n = min(n, p.N - 4);
-        pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)k * p.ldw + n);
+        R.pb[i] = *reinterpret_cast<const float4*>(wgt + (int64_t)k * p.ldw + n);
       }
     }
   };
 
   const int pro_act = p.pro_act;
   const float pro_slope = p.pro_slope;
-  auto store_step = [&](int stage) {
+  auto store_step = [&](int stage, Regs& R) {
+    if constexpr (PREC == 1) {
+      unsigned char* sa_hi = smem_b + stage * BF_STAGE;
+      unsigned char* sa_lo = sa_hi + BM * 64;
+      unsigned char* sb_hi = sa_lo + BM * 64;
+      unsigned char* sb_lo = sb_hi + BN * 64;
+#pragma unroll
+      for (int i = 0; i < C::A_LD; ++i) {
+        float4 v = sel4((R.a_ok >> i) & 1u, R.pa[i]);
+        if constexpr (ACT == SRN_ACT_LEAKY) {
+          v.x = v.x > 0.f ? v.x : v.x * pro_slope;
+          v.y = v.y > 0.f ? v.y : v.y * pro_slope;
+          v.z = v.z > 0.f ? v.z : v.z * pro_slope;
+          v.w = v.w > 0.f ? v.w : v.w * pro_slope;
+        } else if constexpr (ACT < 0) {
+          v = act4(v, pro_act, pro_slope);
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        const int off = bf_off(lrow + 32 * i, c4 * 4);
+        *reinterpret_cast<bf16x4*>(sa_hi + off) = hi;
+        *reinterpret_cast<bf16x4*>(sa_lo + off) = lo;
+      }
+      if constexpr (!C::NMAJ) {
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+          bf16x4 hi, lo;
+          split4(sel4((R.b_ok >> i) & 1u, R.pb[i]), hi, lo);
+          const int off = bf_off(lrow + 32 * i, c4 * 4);
+          *reinterpret_cast<bf16x4*>(sb_hi + off) = hi;
+          *reinterpret_cast<bf16x4*>(sb_lo + off) = lo;
+        }
+      } else {
+        // n-major source (P.V): transpose while staging -> the same [n][k] image
+        constexpr int F4_PER_ROW = BN / 4;
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) {
+          const int f = tid + i * 256;
+          const int krow = f / F4_PER_ROW;
+          const int nn = (f % F4_PER_ROW) * 4;
+          bf16x4 hi, lo;
+          split4(sel4((R.b_ok >> i) & 1u, R.pb[i]), hi, lo);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int off = bf_off(nn + e, krow);
+            *reinterpret_cast<__bf16*>(sb_hi + off) = hi[e];
+            *reinterpret_cast<__bf16*>(sb_lo + off) = lo[e];
+          }
+        }
+      }
+      return;
+    }
     float* a = As + stage * C::A_STAGE;
     float* b = Bs + stage * C::B_STAGE;
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
-      float4 v = sel4((a_ok >> i) & 1u, pa[i]);
+      float4 v = sel4((R.a_ok >> i) & 1u, R.pa[i]);
       // act(0) == 0 for every supported activation, so masked rows stay zero
       if constexpr (ACT == SRN_ACT_LEAKY) {
         v.x = v.x > 0.f ? v.x : v.x * pro_slope;
@@ -191,14 +273,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
     if constexpr (!C::NMAJ) {
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i)
-        *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDK + c4 * 4) = sel4((b_ok >> i) & 1u, pb[i]);
+        *reinterpret_cast<float4*>(b + (lrow + 32 * i) * LDK + c4 * 4) = sel4((R.b_ok >> i) & 1u, R.pb[i]);
     } else {
       constexpr int F4_PER_ROW = BN / 4;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         const int f = tid + i * 256;
         *reinterpret_cast<float4*>(b + (f / F4_PER_ROW) * C::LDN + (f % F4_PER_ROW) * 4) =
-            sel4((b_ok >> i) & 1u, pb[i]);
+            sel4((R.b_ok >> i) & 1u, R.pb[i]);
       }
     }
   };
@@ -217,14 +299,46 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  load_step(0);
-  store_step(0);
-  __syncthreads();
-
-  for (int step = 0; step < n_steps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < n_steps) load_step(step + 1);  // global loads in flight under the MFMAs
-
+  auto compute = [&](const int cur) {
+    if constexpr (PREC == 1) {
+      const unsigned char* sa_hi = smem_b + cur * BF_STAGE;
+      const unsigned char* sa_lo = sa_hi + BM * 64;
+      const unsigned char* sb_hi = sa_lo + BM * 64;
+      const unsigned char* sb_lo = sb_hi + BN * 64;
+      const int sw = (li >> 2) & 3;  // row swizzle key (tile row offsets are multiples of 32)
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        const int choff = (((kk * 2 + lh) ^ sw) & 3) << 4;
+        bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int o = (wm0 + m * 32 + li) * 64 + choff;
+          ah[m] = *reinterpret_cast<const bf16x8*>(sa_hi + o);
+          al[m] = *reinterpret_cast<const bf16x8*>(sa_lo + o);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int o = (wn0 + n * 32 + li) * 64 + choff;
+          bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + o);
+          bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + o);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+      }
+    } else {
     const float* a = As + cur * C::A_STAGE + (wm0 + li) * LDK + 4 * lh;
     const float* b = C::NMAJ ? Bs + cur * C::B_STAGE + (4 * lh) * C::LDN + wn0 + li
                              : Bs + cur * C::B_STAGE + (wn0 + li) * LDK + 4 * lh;
@@ -261,8 +375,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
     }
-    if (step + 1 < n_steps) store_step(cur ^ 1);
+    }
+  };
+
+  // Pipeline: LDS double-buffered; while tile s is multiplied out of LDS[s & 1], tile s+1 is in flight from
+  // global memory into registers and is staged (activation / split / ds_write) after the MFMA phase.
+  // (A second register set = prefetch distance 2 was measured: +3 % only, and the 2x-unrolled loop made hipcc
+  // shuffle the 64 accumulator registers every iteration.)
+  if constexpr (PREC == 1) {
+    // split-bf16: the MFMA phase is short (24 x 32 cycles), so the staging VALU work (split + ds_write) of the
+    // NEXT tile must overlap it inside the same wave: tile s+1 already sits in one register set (its loads were
+    // issued a whole iteration earlier) while tile s+2 is being fetched into the other.
+    Regs R1;
+    // MFMA phase of tile s and staging of tile s+1 in ONE basic block, interleaved by the scheduler:
+    // per MFMA (32 cycles, 8 of which block vector issue) ~7 VALU + LDS traffic ride along.
+    auto fused = [&](const int cs, const int ss, Regs& R) {
+      compute(cs);
+      store_step(ss, R);
+      constexpr int N_MFMA = MT * NT * 6;
+      constexpr int N_DSR = (MT + NT) * 4;
+      constexpr int VPM = ((C::A_LD + C::B_LD) * 20 + N_MFMA - 1) / N_MFMA;
+      __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * 2, 0);  // fragments of the first k16 step
+#pragma unroll
+      for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < N_DSR - (MT + NT) * 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    };
+    load_step(0, R0);
+    store_step(0, R0);
+    if (n_steps > 1) load_step(1, R0);
     __syncthreads();
+    int step = 0;
+    // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (if it exists)
+    for (; step + 2 < n_steps; step += 2) {
+      load_step(step + 2, R1);
+      fused(0, 1, R0);
+      __syncthreads();
+      if (step + 3 < n_steps) load_step(step + 3, R0);
+      fused(1, 0, R1);
+      __syncthreads();
+    }
+    compute(0);
+    if (step + 1 < n_steps) {
+      store_step(1, R0);
+      __syncthreads();
+      compute(1);
+    }
+  } else {
+    load_step(0, R0);
+    store_step(0, R0);
+    __syncthreads();
+    for (int step = 0; step < n_steps; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < n_steps) load_step(step + 1, R0);
+      compute(cur);
+      if (step + 1 < n_steps) store_step(cur ^ 1, R0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
@@ -338,28 +510,38 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
 
 struct TileInfo {
   int id, bm, bn, wn;
-  float base;  // relative efficiency prior of the tile shape
+  float base[2];  // measured relative efficiency of the tile shape on large grids: [fp32, split-bf16]
 };
 // id: 1 128x128 (64x64/wave) | 2 128x64 (32x64) | 3 64x128 (32x64) | 4 64x64 (32x32) | 5 128x32 (32x32)
-const TileInfo kTiles[] = {{1, 128, 128, 64, 1.00f}, {2, 128, 64, 64, 0.93f}, {3, 64, 128, 64, 0.93f},
-                           {4, 64, 64, 32, 0.80f},   {5, 128, 32, 32, 0.78f}};
+// (priors from tools/opbench.py --sweep on MI355X: in fp32 the MFMA phase is long and the small tile loses nothing;
+//  in split-bf16 the kernel is L2-traffic sensitive and bigger tiles win)
+const TileInfo kTiles[] = {{1, 128, 128, 64, {1.00f, 1.00f}}, {2, 128, 64, 64, {0.90f, 0.95f}},
+                           {3, 64, 128, 64, {0.92f, 0.97f}},  {4, 64, 64, 32, {0.97f, 0.85f}},
+                           {5, 128, 32, 32, {0.85f, 0.75f}}};
 
-template <class C, int ACT>
-int launch_act(const SrnConvParams& p, hipStream_t stream) {
+template <class C, int ACT, int PREC>
+int launch_prec(const SrnConvParams& p, hipStream_t stream) {
+  constexpr int SMEM = PREC == 1 ? 2 * (C::BM + C::BN) * 128 : C::SMEM_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C, ACT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES));
+    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C, ACT, PREC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
   SRN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_gemm: bad grid %lld", (long long)blocks);
-  hipLaunchKernelGGL((conv_gemm_kernel<C, ACT>), dim3((unsigned)blocks), dim3(256), C::SMEM_BYTES, stream, p, m_tiles,
+  hipLaunchKernelGGL((conv_gemm_kernel<C, ACT, PREC>), dim3((unsigned)blocks), dim3(256), SMEM, stream, p, m_tiles,
                      n_tiles);
   SRN_CHECK_LAUNCH();
   return 0;
+}
+
+template <class C, int ACT>
+int launch_act(const SrnConvParams& p, hipStream_t stream) {
+  if (p.precision == SRN_PREC_BF16X3) return launch_prec<C, ACT, 1>(p, stream);
+  return launch_prec<C, ACT, 0>(p, stream);
 }
 
 template <class C>
@@ -381,8 +563,10 @@ int pick_tile(const SrnConvParams& p) {
     const double blocks = z * mt * nt;
     const double useful = ((double)p.T_out * p.N) / (mt * t.bm * nt * t.bn);
     const double rounds = (blocks + 255.0) / 256.0;
-    const double quant = blocks / (256.0 * (double)(int64_t)rounds);
-    const float score = (float)(useful * (quant < 1.0 ? quant : 1.0)) * t.base;
+    double quant = blocks / (256.0 * (double)(int64_t)rounds);
+    // fewer blocks than CUs idles CUs outright; beyond one round, co-resident blocks absorb part of the tail
+    if (blocks > 256.0) quant = 0.35 + 0.65 * quant;
+    const float score = (float)(useful * quant) * t.base[p.precision == SRN_PREC_BF16X3 ? 1 : 0];
     if (score > best) {
       best = score;
       best_id = t.id;

@@ -188,7 +188,7 @@ class Decoder(_Packed):
         return P
 
     def plan(self, B, L, n_steps, euler):
-        key = (B, L, n_steps, bool(euler))
+        key = (B, L, n_steps, bool(euler), ops.DEFAULT_PRECISION)
         if key not in self._plans:
             if len(self._plans) > 8:
                 self._plans.clear()

@@ -121,7 +121,7 @@ class HiFiGANGenerator(_Packed):
         return self._packed
 
     def plan(self, B, T):
-        key = (B, T)
+        key = (B, T, ops.DEFAULT_PRECISION)
         if key not in self._plans:
             if len(self._plans) > 4:
                 self._plans.clear()

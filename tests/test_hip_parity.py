@@ -16,11 +16,31 @@ from serenade_amd.utils.synth import HIFIGAN_PARAMS, SERENADE_PARAMS, fill_state
 from tests import _emulator
 from tests._weights import hifigan_weights, serenade_weights, sub
 
+import serenade_amd
+
 pytestmark = pytest.mark.gpu
 
-KTOL = 2e-5
 MEL_RTOL = 1e-3
 WAVE_ATOL = 1e-4
+
+
+class _Tol:
+    """kernel-level tolerance (fraction of the tensor's max) of the active contraction precision:
+    exact-fp32 MFMA differs from the CPU only by summation order; split-bf16 carries ~2^-17 per product."""
+    k = 2e-5
+    model = 1e-4
+
+
+KTOL = _Tol
+
+
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+def precision(request):
+    serenade_amd.set_precision(request.param)
+    _Tol.k = 2e-5 if request.param == "fp32" else 1e-4
+    _Tol.model = 1e-4 if request.param == "fp32" else MEL_RTOL
+    yield request.param
+    serenade_amd.set_precision("bf16x3")
 
 
 def T(a):
@@ -59,9 +79,10 @@ class Mirror:
         return list(self.map.values())
 
 
-def run_conv_both(dev, kw, tol=KTOL, tiles=(0,)):
+def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     """run the kernel (for each tile id) and the spec on clones of the same inputs; compare every buffer"""
     base = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    tol = KTOL.k if tol is None else tol
     for tile in tiles:
         cpu = {}
         memo = {}
@@ -125,7 +146,7 @@ def test_conv_k3_mask_and_gn_partials(dev):
     ops.ConvOp(**g)()
     mask = (torch.arange(Tn)[None] < kw["len_in"][:, None]).float().unsqueeze(-1)
     ref = F.conv1d((x * mask).transpose(1, 2), rnd(N, C, 3, seed=5), kw["bias"], padding=1).transpose(1, 2)
-    assert nerr(g["out"], ref) < KTOL
+    assert nerr(g["out"], ref) < KTOL.k
 
 
 def test_conv_k7_reflect_leaky_and_dilated_k11(dev):
@@ -140,7 +161,7 @@ def test_conv_k7_reflect_leaky_and_dilated_k11(dev):
     g = {k: m(v) for k, v in kw.items()}
     ops.ConvOp(**g)()
     ref = F.conv1d(F.pad(F.leaky_relu(x, 0.2).transpose(1, 2), (3, 3), mode="reflect"), w7, kw["bias"]).transpose(1, 2)
-    assert nerr(g["out"], ref) < KTOL
+    assert nerr(g["out"], ref) < KTOL.k
     w11 = rnd(N, C, 11, seed=10)
     kw2 = dict(kw, w=ops.pack_conv_weight(w11), ldw=11 * C, taps=ops.conv_taps(11, 5), reflect=False,
                pro_slope=0.1, out=torch.zeros(B, Tn, N))
@@ -149,7 +170,7 @@ def test_conv_k7_reflect_leaky_and_dilated_k11(dev):
     g = {k: m(v) for k, v in kw2.items()}
     ops.ConvOp(**g)()
     ref = F.conv1d(F.leaky_relu(x, 0.1).transpose(1, 2), w11, kw["bias"], dilation=5, padding=25).transpose(1, 2)
-    assert nerr(g["out"], ref) < KTOL
+    assert nerr(g["out"], ref) < KTOL.k
 
 
 def test_conv_stride2_and_concat(dev):
@@ -170,7 +191,7 @@ def test_conv_stride2_and_concat(dev):
     g = {k: m(v) for k, v in kw2.items()}
     ops.ConvOp(**g)()
     ref = F.conv1d(torch.cat([x, s], -1).transpose(1, 2), wc, None, padding=1).transpose(1, 2)
-    assert nerr(g["out"], ref) < KTOL
+    assert nerr(g["out"], ref) < KTOL.k
 
 
 def test_geglu_epilogue(dev):
@@ -185,7 +206,7 @@ def test_geglu_epilogue(dev):
     g = {k: m(v) for k, v in kw.items()}
     ops.ConvOp(**g)()
     h, gate = (x @ w.t() + b).chunk(2, -1)
-    assert nerr(g["out"], h * F.gelu(gate)) < KTOL
+    assert nerr(g["out"], h * F.gelu(gate)) < KTOL.k
 
 
 def test_residual_modes_inplace(dev):
@@ -229,7 +250,7 @@ def test_attention_batched_gemms(dev):
     ops.ConvOp(**g)()
     v = qkv[:, :, 2 * inner:].view(B, L, H, d).permute(0, 2, 1, 3)
     ref = (P[:, :, :L].view(B, H, L, L) @ v).permute(0, 2, 1, 3).reshape(B, L, inner)
-    assert nerr(g["out"], ref) < KTOL
+    assert nerr(g["out"], ref) < KTOL.k
 
 
 @pytest.mark.parametrize("stride,k", [(2, 4), (8, 16), (5, 10), (3, 6)])
@@ -249,7 +270,7 @@ def test_conv_transpose_phases(dev, stride, k):
         ops.ConvOp(in0=xd, w=wp.to(dev), bias=bd, out=out, n_batch=B, T_in=Tn, T_out=rows, C_in=Ci, N=Co,
                    in0_bs=Tn * Ci, ld_in0=Ci, ldw=wp.shape[1], out_bs=To * Co, ld_out=Co, taps=taps,
                    pro_act=_lib.ACT_LEAKY, pro_slope=0.1, out_t_stride=stride, out_t_off=r)()
-    assert nerr(out, ref) < KTOL
+    assert nerr(out, ref) < KTOL.k
 
 
 def test_prologue_silu_mish(dev):
@@ -290,23 +311,23 @@ def test_norm_and_elementwise_kernels(dev):
     gam, bet, tb = 1 + 0.1 * rnd(C, seed=34), 0.1 * rnd(C, seed=35), rnd(4 * C, seed=36)
     e = _run_call(dev, "srn_gn_mish_apply", [x, _partials(x), gam, bet, (tb, C), 0, lens, torch.zeros(B, Tn, C), B,
                                              Tn, C, 8, 1e-5])
-    assert e < KTOL
+    assert e < KTOL.k
     # against torch's GroupNorm directly (statistics over the padded length)
     y = torch.zeros(B, Tn, C, device=dev)
     ops.gn_mish_apply_op(x.to(dev), _partials(x).to(dev), gam.to(dev), bet.to(dev), None, lens.to(dev), y, B, Tn, C)()
     mask = (torch.arange(Tn)[None] < lens[:, None]).float().unsqueeze(-1)
     ref = F.mish(F.group_norm(x.transpose(1, 2), 8, gam, bet, 1e-5)).transpose(1, 2) * mask
-    assert nerr(y, ref) < KTOL
+    assert nerr(y, ref) < KTOL.k
     ss = rnd(B, 4 * C, seed=37)
     e = _run_call(dev, "srn_resblock_tail", [x, _partials(x), gam, bet, lens, rnd(B, Tn, C, seed=38), (ss, C),
                                              (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5])
-    assert e < KTOL
+    assert e < KTOL.k
     e = _run_call(dev, "srn_layernorm", [x.reshape(-1, C), gam, bet, torch.zeros(B * Tn, C), B * Tn, C, 1e-5])
-    assert e < KTOL
+    assert e < KTOL.k
     for L, ld in ((70, 72), (300, 300), (1280, 1280), (2176, 2176)):
         s = rnd(4, L, ld, seed=39) * 3
         e = _run_call(dev, "srn_softmax_rows", [s, torch.tensor([L, max(1, L - 9)], dtype=torch.int32), 4, 2, L, ld])
-        assert e < KTOL
+        assert e < KTOL.k
     t = torch.tensor([0.0, 0.1, 0.3, 0.9], dtype=torch.float32)
     e = _run_call(dev, "srn_sinusoidal_emb", [t, torch.zeros(4, 256), 4, 242, 256, 1000.0])
     assert e < 2e-4  # sin/cos of arguments up to 1e3: 1 ulp of the argument is ~6e-5
@@ -323,7 +344,7 @@ def test_norm_and_elementwise_kernels(dev):
     for C2, k in ((32, 7), (16, 5)):
         e = _run_call(dev, "srn_out_conv_tanh", [rnd(2, 300, C2, seed=45), rnd(k, C2, seed=46) * 0.2, rnd(1, seed=47),
                                                  torch.zeros(2, 300), 2, 300, C2, k, 0.01])
-        assert e < KTOL
+        assert e < KTOL.k
 
 
 def test_gst_kernels(dev):
@@ -337,18 +358,18 @@ def test_gst_kernels(dev):
         y = torch.zeros(B, Ho, Wo, co)
         e = _run_call(dev, "srn_conv2d_bn_relu", [x, w, 1 + 0.1 * rnd(co, seed=52), 0.1 * rnd(co, seed=53), y, B, H, W,
                                                   ci, co])
-        assert e < KTOL
+        assert e < KTOL.k
         x = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), stride=2, padding=1)).permute(0, 2, 3, 1)
         x = x.contiguous()
         H, W = Ho, Wo
     e = _run_call(dev, "srn_gru_last", [rnd(2, 3, 1024, seed=54), rnd(384, 1024, seed=55) / 32, rnd(384, 128, seed=56) / 11,
                                         0.1 * rnd(384, seed=57), 0.1 * rnd(384, seed=58), torch.zeros(2, 128), 2, 3,
                                         1024, 128])
-    assert e < KTOL
+    assert e < KTOL.k
     a = [rnd(2, 128, seed=59), 0.5 * rnd(50, 64, seed=60), rnd(256, 128, seed=61) / 11, 0.1 * rnd(256, seed=62),
          rnd(256, 64, seed=63) / 8, 0.1 * rnd(256, seed=64), rnd(256, 64, seed=65) / 8, 0.1 * rnd(256, seed=66),
          rnd(256, 256, seed=67) / 16, 0.1 * rnd(256, seed=68), torch.zeros(2, 256), 2, 128, 50, 64, 256, 4]
-    assert _run_call(dev, "srn_style_token_attention", a) < KTOL
+    assert _run_call(dev, "srn_style_token_attention", a) < KTOL.k
 
 
 # ------------------------------------------------------------------------------------------------
@@ -378,7 +399,7 @@ def test_decoder_forward_golden(dev, model, golden, tag):
     mask = O.make_non_pad_mask(g["lens"].tolist()).unsqueeze(1).to(dev)
     out = model.cfm_decoder.estimator(T(g["x"]).to(dev), mask, T(g["mu"]).to(dev), T(g["t"]).to(dev),
                                       T(g["spk"]).to(dev))
-    assert nerr(out, g["out"]) < 1e-4
+    assert nerr(out, g["out"]) < KTOL.model
 
 
 def test_euler_golden(dev, model, golden):
@@ -391,7 +412,7 @@ def test_euler_golden(dev, model, golden):
 
 def test_encoder_gst_golden(dev, model, golden):
     g = golden("encoder")
-    assert nerr(model.encoder(T(g["x"]).to(dev)), g["y"]) < 5e-5
+    assert nerr(model.encoder(T(g["x"]).to(dev)), g["y"]) < 5 * KTOL.k
     g = golden("gst")
     assert nerr(model.gst(T(g["speech"]).to(dev)), g["style"]) < 5e-5
 
@@ -414,7 +435,7 @@ def test_inference_and_vocoder_golden(dev, model, voc, golden):
     mel2 = _infer(model, d, dev, noise=(d["z"] / 0.667) * 0.667)
     assert nerr(mel2, g["mel_b2"]) < MEL_RTOL
     y = voc[0].model(T(gh["c"]).to(dev))
-    assert nerr(y, gh["y"]) < 1e-4
+    assert nerr(y, gh["y"]) < KTOL.model
 
 
 def test_hifigan_small_variant_golden(dev, golden):
@@ -423,7 +444,7 @@ def test_hifigan_small_variant_golden(dev, golden):
     gen = vocoder.HiFiGANGenerator(**dict(params, use_weight_norm=False))
     gen.load_state_dict(w)
     y = gen.to(dev)(T(g["c"]).to(dev))
-    assert nerr(y, g["y"]) < 1e-4
+    assert nerr(y, g["y"]) < KTOL.model
 
 
 def test_cpu_generator_noise_matches_reference_semantics(dev, model):
@@ -486,4 +507,4 @@ def test_long_form_T4096_runs_and_matches_oracle_prefix(dev, model):
     mask = torch.ones(B, 1, L, dtype=torch.bool)
     out = model.cfm_decoder.estimator(x.to(dev), mask.to(dev), mu.to(dev), torch.tensor(0.5), spk.to(dev))
     ref = O.decoder_forward(sub(serenade_weights(), "cfm_decoder.estimator."), x, mask, mu, torch.tensor(0.5), spk)
-    assert nerr(out, ref) < 1e-4
+    assert nerr(out, ref) < KTOL.model

@@ -52,7 +52,42 @@ def report(title, agg):
               f"{cnt:3d} {ms / cnt:8.3f} {fl * cnt / (ms * 1e-3) / 1e12:6.1f} {ms / tot * 100:6.1f}%")
 
 
+def sweep(oplist, reps=5):
+    """time every distinct shape under every admissible tile id"""
+    seen = {}
+    for op in oplist:
+        if isinstance(op, ops.ConvOp) and sig(op.kw) not in seen:
+            seen[sig(op.kw)] = op
+    print(f"{'Z':>4} {'T_out':>7} {'N':>5} {'K':>6} taps nmaj geglu |  auto    t1     t2     t3     t4     t5   (TF/s)")
+    for k, op in seen.items():
+        Z, T, N, K, taps, nmaj, geglu, st, gn, act = k
+        fl = 2.0 * Z * T * N * K
+        res = []
+        for tile in (0, 1, 2, 3, 4, 5):
+            if tile in (2, 5) and nmaj:
+                res.append(float("nan"))
+                continue
+            if geglu and tile in (4, 5):
+                res.append(float("nan"))
+                continue
+            o2 = ops.ConvOp(**dict(op.kw, tile=tile))
+            o2()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                o2()
+            e.record()
+            torch.cuda.synchronize()
+            res.append(fl / (s.elapsed_time(e) / reps * 1e-3) / 1e12)
+        print(f"{Z:4d} {T:7d} {N:5d} {K:6d} {taps:4d} {int(nmaj):4d} {int(geglu):5d} | " +
+              " ".join(f"{r:6.1f}" for r in res))
+
+
 def main():
+    if "--bf16x3" in sys.argv:
+        from serenade_amd import _lib
+        ops.DEFAULT_PRECISION = _lib.PREC_BF16X3
     dev = torch.device("cuda:0")
     model, voc, sd, gsd = bench.build_models(dev)
     B, T, Tr = bench.B_PER_GPU, bench.T_SRC, bench.T_REF
@@ -64,6 +99,10 @@ def main():
     voc.decode_batch(mel)
     torch.cuda.synchronize()
     pl = model.cfm_decoder.estimator.plan(B, T + Tr, 10, euler=True)
+    if "--sweep" in sys.argv:
+        sweep(pl.steps[0])
+        sweep(voc.model.plan(B, T).ops)
+        return
     report("one Euler step (x10 per utterance batch)", time_ops(pl.steps[0]))
     vp = voc.model.plan(B, T)
     report("HiFi-GAN forward", time_ops(vp.ops))
