@@ -225,7 +225,8 @@ def test_residual_modes_inplace(dev):
     run_conv_both(dev, dict(common, out=h0, out_bs=Tn * 48, ld_out=48, res=h0, res_mode=_lib.RES_AXPY, beta=0.1,
                             res_bs=Tn * 48, ld_res=48, len_out=torch.tensor([40, 17], dtype=torch.int32)),
                   tiles=(0, 4, 5))
-    run_conv_both(dev, dict(common, out=torch.zeros(B, Tn, N), post=_lib.POST_TANH), tiles=(0,))
+    # tanh output: weights scaled so that the pre-activations are O(1) (error is judged on the tanh output)
+    run_conv_both(dev, dict(common, w=w * 0.1, out=torch.zeros(B, Tn, N), post=_lib.POST_TANH), tiles=(0,))
 
 
 def test_attention_batched_gemms(dev):
