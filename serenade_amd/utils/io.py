@@ -44,3 +44,67 @@ def write_hdf5(hdf5_name, hdf5_path, write_data, is_overwrite=True):
             logging.warning("Dataset in hdf5 file already exists. recreate dataset in hdf5.")
             del f[hdf5_path]
         f.create_dataset(hdf5_path, data=write_data)
+
+
+# ---------------------------------------------------------------------------------------------
+# Feature files.  The reference stores one HDF5 per utterance with datasets
+# wave, hubert, logmel, loud, est_lf0_score / gt_lf0_score, f0, midi (preprocess.py:567-611).  The same keys in
+# a NumPy ".npz" archive are accepted too (handy where h5py is not installed).
+def read_feats(path, key):
+    if path.endswith(".npz"):
+        if not os.path.exists(path):
+            logging.error(f"There is no such a feature file ({path}).")
+            return None
+        with np.load(path) as f:
+            if key not in f:
+                logging.error(f"There is no such a data in feature file. ({key})")
+                return None
+            return f[key]
+    return read_hdf5(path, key)
+
+
+def write_feats(path, key, data):
+    if path.endswith(".npz"):
+        old = {}
+        if os.path.exists(path):
+            with np.load(path) as f:
+                old = {k: f[k] for k in f.files}
+        old[key] = np.asarray(data)
+        np.savez(path, **old)
+        return
+    write_hdf5(path, key, data)
+
+
+def find_files(root_dir, query="*.h5", include_root_dir=True):
+    """serenade/utils/utils.py:27-43."""
+    import fnmatch
+    files = []
+    for root, _, filenames in os.walk(root_dir, followlinks=True):
+        for filename in fnmatch.filter(filenames, query):
+            files.append(os.path.join(root, filename))
+    if not include_root_dir:
+        files = [f.replace(root_dir + "/", "") for f in files]
+    return files
+
+
+def write_wav_pcm16(path, wave, sr):
+    """`soundfile.write(path, wave, sr, "PCM_16")` (ssc_decode.py:361-366,449-455); falls back to the stdlib
+    `wave` module with libsndfile's float -> int16 rule (scale 32767... clip, round-to-nearest) when soundfile is
+    not installed."""
+    x = np.asarray(wave)
+    try:
+        import soundfile as sf
+        sf.write(path, x, sr, "PCM_16")
+        return
+    except ImportError:
+        pass
+    import wave as _wave
+    if x.dtype.kind == "f":
+        x = np.clip(np.rint(x.astype(np.float64) * 32768.0), -32768, 32767).astype("<i2")
+    else:
+        x = x.astype("<i2")
+    with _wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(int(sr))
+        f.writeframes(x.tobytes())

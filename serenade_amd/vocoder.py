@@ -265,8 +265,8 @@ class Vocoder(object):
             cfg = yaml.load(f, Loader=yaml.Loader)
         model = load_vocoder(checkpoint, cfg)
         logging.info(f"Loaded model parameters from {checkpoint}.")
-        from .utils.io import read_hdf5
-        st = {"mean": read_hdf5(stats, "mean"), "scale": read_hdf5(stats, "scale")}
+        from .utils.io import read_feats  # .h5 (h5py) like the reference, or .npz with the same keys
+        st = {"mean": read_feats(stats, "mean"), "scale": read_feats(stats, "scale")}
         self._setup(model, cfg, st, device, trg_stats, take_norm_feat)
 
     @classmethod
