@@ -338,6 +338,45 @@ def serenade_inference(w, x, lengths, midi, lft, ref_x, ref_lengths, ref_logmel,
     return mel.squeeze(0)
 
 
+# --------------------------------------------------------------------------- a1' training-loss forward
+def cfm_compute_loss(w, x1, mask, mu, spk, mask_l, t, z, sigma_min=1e-4):
+    """CFM.compute_loss, flow_matching.py:95-133, with the random draws (t (B,1,1), z like x1) made explicit."""
+    y = (1 - (1 - sigma_min) * t) * z + t * x1
+    u = x1 - (1 - sigma_min) * z
+    den = decoder_forward(w, y, mask, mu, t.squeeze(), spk)
+    if mask_l is not None:
+        den = den * mask_l
+        u = u * mask_l
+    loss = F.mse_loss(den, u, reduction="sum")
+    denom = (torch.sum(mask_l) if mask_l is not None else torch.sum(mask)) * u.shape[1]
+    return loss / denom, y
+
+
+def serenade_forward(w, x, lengths, logmel, midi, lft, uniform, seg_start, t, z, mask_size=(0.1, 0.5)):
+    """Serenade.forward, serenade/models/serenade.py:90-166.  `uniform` is the value random.uniform(*mask_size)
+    returned, `seg_start` the value of random.randint, (t, z) the draws of CFM.compute_loss."""
+    ret = {}
+    enc = conv1d_resnet(_sub(w, "encoder."), x)
+    ret["gauss_mel"] = enc
+    spk = style_encoder(_sub(w, "gst."), logmel)
+    mask = make_non_pad_mask(lengths).unsqueeze(1)
+    msize = int(uniform * enc.size(1))
+    seg_end = seg_start + msize
+    mask_l = mask.clone()
+    mask_l[:, :, 0:seg_start] = 0
+    mask_l[:, :, seg_end:] = 0
+    mask_c = mask.clone()
+    mask_c[:, :, seg_start:seg_end] = 0
+    prior = torch.sum(0.5 * ((logmel.permute(0, 2, 1) - enc.permute(0, 2, 1)) ** 2 + math.log(2 * math.pi)) * mask)
+    ret["prior_loss"] = prior / (torch.sum(mask) * logmel.shape[-1])
+    targets = logmel * mask_l.permute(0, 2, 1)
+    cond = logmel * mask_c.permute(0, 2, 1)
+    mu = torch.cat([enc, midi, lft, cond], dim=-1)
+    ret["cfm_loss"], _ = cfm_compute_loss(_sub(w, "cfm_decoder.estimator."), targets.permute(0, 2, 1), mask,
+                                          mu.permute(0, 2, 1), spk, mask_l, t, z)
+    return ret
+
+
 # --------------------------------------------------------------------------- a8 HiFi-GAN
 def hifigan_residual_block(w, x, kernel_size, dilations, slope=0.1):
     """HiFiGANResidualBlock.forward, serenade/vocoder/layers/residual_block.py:243-258."""

@@ -187,22 +187,27 @@ class Decoder(_Packed):
         self._packed = P
         return P
 
-    def plan(self, B, L, n_steps, euler):
-        key = (B, L, n_steps, bool(euler), ops.DEFAULT_PRECISION)
+    def plan(self, B, L, n_steps, euler, per_sample_t=False):
+        key = (B, L, n_steps, bool(euler), bool(per_sample_t), ops.DEFAULT_PRECISION)
         if key not in self._plans:
             if len(self._plans) > 8:
                 self._plans.clear()
-            self._plans[key] = DecoderPlan(self, B, L, n_steps, euler)
+            self._plans[key] = DecoderPlan(self, B, L, n_steps, euler, per_sample_t)
         return self._plans[key]
 
     @torch.no_grad()
     def forward(self, x, mask, mu, t, speaker_features):
-        """decoder.py:384-467.  x (B, out_ch, L), mask (B, 1, L), mu (B, cond, L), t 0-dim, spk (B, S)."""
+        """decoder.py:384-467.  x (B, out_ch, L), mask (B, 1, L), mu (B, cond, L), spk (B, S);
+        t is 0-dim (one time for the batch, as solve_euler passes it) or (B,) (one per sample, as
+        CFM.compute_loss passes it)."""
         _require_cuda(x, "Decoder.forward")
         B, _, L = x.shape
-        pl = self.plan(B, L, 1, euler=False)
+        t = torch.as_tensor(t)
+        per_sample = t.ndim >= 1 and t.numel() == B and B > 1
+        pl = self.plan(B, L, 1, euler=False, per_sample_t=per_sample)
         lens = mask.reshape(B, -1).to(torch.int64).sum(dim=1)
-        pl.set_inputs(x, mu, speaker_features, lens, ts=[float(t)])
+        ts = [float(v) for v in t.reshape(-1).tolist()] if per_sample else [float(t.reshape(-1)[0])]
+        pl.set_inputs(x, mu, speaker_features, lens, ts=ts)
         pl.run()
         return pl.read_out()
 
@@ -214,10 +219,16 @@ class DecoderPlan:
                  (flow_matching.py:84-91), written in place into channels [0, out_ch) of h0.
     euler=False: one estimator call, output (B, L, out_ch) in ``self.dphi``."""
 
-    def __init__(self, dec, B, L, n_steps, euler):
+    def __init__(self, dec, B, L, n_steps, euler, per_sample_t=False):
         P = dec.packed()
         dev = dec._device()
-        self.dec, self.B, self.L, self.n, self.euler = dec, B, L, n_steps, euler
+        # per_sample_t: ONE estimator call whose time embedding has one row per batch item
+        # (CFM.compute_loss draws t per sample, flow_matching.py:116,123); otherwise one row per Euler step.
+        self.per_sample_t = bool(per_sample_t)
+        n_iter = 1 if per_sample_t else n_steps
+        n_steps = B if per_sample_t else n_steps  # rows of the time-embedding buffers below
+        self.n_rows = n_steps
+        self.dec, self.B, self.L, self.n, self.euler = dec, B, L, n_iter, euler
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         D = len(dec.channels)
         Ts = [L]
@@ -297,7 +308,7 @@ class DecoderPlan:
             ol.append(conv(xin, cin, T, r["c1_w"], r["c1_b"], bufC, C, T, t3, ld_in=ld_in, len_in=ln,
                            gn_partials=gnp, **extra))
             ol.append(ops.gn_mish_apply_op(bufC, gnp, r["g1_w"], r["g1_b"], (self.tb, k * tb_ld + tb_off[bi]), ln,
-                                           bufA, B, T, C))
+                                           bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0))
             ol.append(conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp))
             ol.append(conv(xin, cin, T, r["r_w"], r["r_b"], bufR, C, T, [0], ld_in=ld_in, len_in=ln, **extra))
             ol.append(ops.resblock_tail_op(bufC, gnp, r["g2_w"], r["g2_b"], ln, bufR, (self.ss, ss_off[bi]),
@@ -408,7 +419,7 @@ class DecoderPlan:
     # ------------------------------------------------------------------
     def set_schedule(self, ts, dts):
         """ts/dts: python floats (already fp32-rounded).  Rebuilds the per-step op lists if dt changed."""
-        assert len(ts) == self.n
+        assert len(ts) == self.n_rows
         self.t_dev.copy_(torch.tensor(ts, dtype=torch.float32), non_blocking=False)
         dts = [0.0] * self.n if dts is None else list(dts)
         if self.steps is None or self._dts != dts:
@@ -478,9 +489,31 @@ class CFM(_Packed):
                                  channels=decoder_channels, attention_head_dim=decoder_attention_head_dim)
 
     def forward(self, x1, mask, mu, spks, mask_l=None):
-        raise NotImplementedError(
-            "CFM.forward (training loss, flow_matching.py:95-133) needs backward kernels: out of scope for the "
-            "inference hot path")
+        return self.compute_loss(x1, mask, mu, spks, mask_l)
+
+    @torch.no_grad()
+    def compute_loss(self, x1, mask, mu, spks, mask_l=None, draws=None):
+        """Forward value of the conditional flow-matching loss, flow_matching.py:95-133 (no autograd: the
+        backward pass is outside this build's scope).  The estimator call -- all of the arithmetic that matters --
+        runs on the HIP kernels with one time value per sample; the O(B*80*L) interpolation and the scalar
+        reductions around it use torch on the same device.  `draws` = {"t": (B,1,1), "z": like x1} overrides
+        the random draws (parity tests)."""
+        _require_cuda(x1, "CFM.compute_loss")
+        b = mu.shape[0]
+        if draws is None:
+            t = torch.rand([b, 1, 1], device=mu.device, dtype=mu.dtype)
+            z = torch.randn_like(x1)
+        else:
+            t, z = draws["t"].to(x1), draws["z"].to(x1)
+        y = (1 - (1 - self.sigma_min) * t) * z + t * x1
+        u = x1 - (1 - self.sigma_min) * z
+        denoised = self.estimator(y, mask, mu, t.squeeze(), spks)
+        if mask_l is not None:
+            denoised = denoised * mask_l
+            u = u * mask_l
+        loss = torch.nn.functional.mse_loss(denoised, u, reduction="sum")
+        denom = torch.sum(mask_l) if mask_l is not None else torch.sum(mask)
+        return loss / (denom * u.shape[1]), y
 
     @torch.inference_mode()
     def inference(self, mu, mask, n_timesteps=10, temperature=0.667, spks=None):
@@ -662,10 +695,39 @@ class Serenade(_Packed):
                                decoder_attention_head_dim=decoder_attention_head_dim)
         self.mask_size = mask_size
 
-    def forward(self, x, lengths, logmel, midi, lft):
-        raise NotImplementedError(
-            "Serenade.forward is the training loss (serenade.py:90-166); its backward pass is outside the "
-            "inference hot path this build covers.  Use inference().")
+    @torch.no_grad()
+    def forward(self, x, lengths, logmel, midi, lft, draws=None):
+        """Forward value of the training objective, serenade.py:90-166: returns
+        {"gauss_mel", "prior_loss", "cfm_loss"} like the reference (values only -- no autograd graph; training /
+        backward is out of scope).  Encoder, GST and the estimator run on the HIP kernels; the infill-mask
+        bookkeeping and the scalar reductions use torch on the same device.  `draws` (tests) may carry
+        {"uniform", "seg_start", "t", "z"} to replace the random draws."""
+        import random
+        _require_cuda(x, "Serenade.forward")
+        ret = {}
+        enc_outs = self.encoder(x, lengths)
+        ret["gauss_mel"] = enc_outs
+        speaker_features = self.gst(logmel)
+        mask = make_non_pad_mask(lengths).to(x.device).unsqueeze(1)
+        uni = random.uniform(self.mask_size[0], self.mask_size[1]) if draws is None else draws["uniform"]
+        mask_size = int(uni * enc_outs.size(1))
+        seg_start = random.randint(0, enc_outs.size(1) - mask_size) if draws is None else int(draws["seg_start"])
+        seg_end = seg_start + mask_size
+        mask_l = mask.clone()
+        mask_l[:, :, 0:seg_start] = 0
+        mask_l[:, :, seg_end:] = 0
+        mask_c = mask.clone()
+        mask_c[:, :, seg_start:seg_end] = 0
+        prior_loss = torch.sum(0.5 * ((logmel.permute(0, 2, 1) - enc_outs.permute(0, 2, 1)) ** 2
+                                      + math.log(2 * math.pi)) * mask)
+        ret["prior_loss"] = prior_loss / (torch.sum(mask) * self.output_dim)
+        targets = logmel * mask_l.permute(0, 2, 1)
+        cond = logmel * mask_c.permute(0, 2, 1)
+        mu = torch.cat([enc_outs, midi, lft, cond], dim=-1)
+        ret["cfm_loss"], _ = self.cfm_decoder.compute_loss(
+            x1=targets.permute(0, 2, 1).contiguous(), mask=mask, mu=mu.permute(0, 2, 1).contiguous(),
+            spks=speaker_features, mask_l=mask_l, draws=draws)
+        return ret
 
     @torch.inference_mode()
     def inference(self, x, lengths, midi, lft, ref_x, ref_lengths, ref_logmel, ref_midi, ref_lft,

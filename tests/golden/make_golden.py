@@ -144,5 +144,58 @@ def main():
     npz("hifigan_small", c=cs, y=gs(cs))
 
 
+def forward_case():
+    """a1' Serenade.forward (training-loss forward, serenade.py:90-166 + flow_matching.py:95-133): capture the
+    random draws the reference makes (python `random` for the infill segment, torch.rand / randn_like for t and z)
+    together with its outputs, so the restatement can be checked on identical draws.
+
+        PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py forward
+    """
+    import random
+    model = Serenade(**SERENADE_PARAMS).eval()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    rng = np.random.default_rng(778)
+    B, Tn = 2, 40
+    lens = [40, 31]
+    x = rnd(rng, B, Tn, 768)
+    logmel = rnd(rng, B, Tn, 80)
+    midi = torch.from_numpy(rng.uniform(0, 1, (B, Tn, 1)).astype(np.float32))
+    lft = torch.from_numpy(rng.uniform(0, 1, (B, Tn, 1)).astype(np.float32))
+    draws = {}
+    o_uniform, o_randint, o_rand, o_randn_like = random.uniform, random.randint, torch.rand, torch.randn_like
+
+    def uniform(a, b):
+        draws["uniform"] = o_uniform(a, b)
+        return draws["uniform"]
+
+    def randint(a, b):
+        draws["seg_start"] = o_randint(a, b)
+        return draws["seg_start"]
+
+    def rand(*a, **k):
+        draws["t"] = o_rand(*a, **k)
+        return draws["t"]
+
+    def randn_like(t, **k):
+        draws["z"] = o_randn_like(t, **k)
+        return draws["z"]
+
+    random.seed(5)
+    torch.manual_seed(5)
+    random.uniform, random.randint, torch.rand, torch.randn_like = uniform, randint, rand, randn_like
+    try:
+        ret = model(x, torch.tensor(lens), logmel, midi, lft)
+    finally:
+        random.uniform, random.randint, torch.rand, torch.randn_like = o_uniform, o_randint, o_rand, o_randn_like
+    npz("forward", lens=np.array(lens), x=x, logmel=logmel, midi=midi, lft=lft, uniform=np.float64(draws["uniform"]),
+        seg_start=np.int64(draws["seg_start"]), t=draws["t"], z=draws["z"], gauss_mel=ret["gauss_mel"],
+        prior_loss=ret["prior_loss"], cfm_loss=ret["cfm_loss"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "forward":
+    forward_case()
+    sys.exit(0)
+
+
 if __name__ == "__main__":
     main()

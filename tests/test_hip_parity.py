@@ -509,3 +509,15 @@ def test_long_form_T4096_runs_and_matches_oracle_prefix(dev, model):
     out = model.cfm_decoder.estimator(x.to(dev), mask.to(dev), mu.to(dev), torch.tensor(0.5), spk.to(dev))
     ref = O.decoder_forward(sub(serenade_weights(), "cfm_decoder.estimator."), x, mask, mu, torch.tensor(0.5), spk)
     assert nerr(out, ref) < KTOL.model
+
+
+def test_training_forward_values_golden(dev, model, golden):
+    """a1' Serenade.forward (loss values; per-sample time embedding) on the reference's own random draws."""
+    g = golden("forward")
+    draws = {"uniform": float(g["uniform"]), "seg_start": int(g["seg_start"]), "t": T(g["t"]).to(dev),
+             "z": T(g["z"]).to(dev)}
+    ret = model(T(g["x"]).to(dev), T(g["lens"]), T(g["logmel"]).to(dev), T(g["midi"]).to(dev), T(g["lft"]).to(dev),
+                draws=draws)
+    assert nerr(ret["gauss_mel"], g["gauss_mel"]) < 5 * KTOL.k
+    assert abs(ret["prior_loss"].item() / float(g["prior_loss"]) - 1) < 1e-4
+    assert abs(ret["cfm_loss"].item() / float(g["cfm_loss"]) - 1) < 1e-3

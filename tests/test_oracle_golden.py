@@ -140,3 +140,14 @@ def test_hifigan_small_variant(golden):
     g = golden("hifigan_small")
     w, cfg = hifigan_weights(seed=1, small=True)
     close(O.hifigan_forward(w, T(g["c"]), cfg), g["y"], 1e-4)
+
+
+def test_training_forward(golden):
+    """a1' Serenade.forward on the reference's own random draws (captured by make_golden.py forward)."""
+    g = golden("forward")
+    w = serenade_weights()
+    ret = O.serenade_forward(w, T(g["x"]), T(g["lens"]), T(g["logmel"]), T(g["midi"]), T(g["lft"]),
+                             float(g["uniform"]), int(g["seg_start"]), T(g["t"]), T(g["z"]))
+    close(ret["gauss_mel"], g["gauss_mel"])
+    assert abs(ret["prior_loss"].item() - float(g["prior_loss"])) <= 1e-5 * abs(float(g["prior_loss"]))
+    assert abs(ret["cfm_loss"].item() - float(g["cfm_loss"])) <= 1e-4 * abs(float(g["cfm_loss"]))

@@ -146,3 +146,15 @@ def test_cpu_tensors_are_refused_without_emulator(model):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.inference(d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"], d["ref_logmel"],
                         d["ref_midi"], d["ref_lft"])
+
+
+def test_training_forward_values(model, golden):
+    """a1' Serenade.forward: loss values on the reference's own random draws (per-sample time embedding)."""
+    g = golden("forward")
+    draws = {"uniform": float(g["uniform"]), "seg_start": int(g["seg_start"]), "t": T(g["t"]), "z": T(g["z"])}
+    with _emulator.installed():
+        ret = model(T(g["x"]), T(g["lens"]), T(g["logmel"]), T(g["midi"]), T(g["lft"]), draws=draws)
+    assert set(ret) == {"gauss_mel", "prior_loss", "cfm_loss"}
+    assert nerr(ret["gauss_mel"], g["gauss_mel"]) < 2e-5
+    assert abs(ret["prior_loss"].item() / float(g["prior_loss"]) - 1) < 1e-5
+    assert abs(ret["cfm_loss"].item() / float(g["cfm_loss"]) - 1) < 1e-4
