@@ -34,7 +34,7 @@ enum { SRN_RES_NONE = 0, SRN_RES_ADD = 1, SRN_RES_AXPY = 2 };
 /* post op */
 /* arithmetic of the contraction */
 enum { SRN_PREC_FP32 = 0 /* exact fp32 MFMA */, SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */ };
-enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2 };
+enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2, SRN_POST_RELU = 3 };
 
 /*
  * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors, computed with the exact-fp32
@@ -84,7 +84,7 @@ typedef struct SrnConvParams {
   const float* bias;
   const int32_t* len_in;   /* per zb, or NULL */
   const int32_t* len_out;  /* per zb, or NULL: output rows t >= len_out are multiplied by 0 */
-  const float* res;  int64_t res_bs; int32_t ld_res;
+  const float* res;  int64_t res_bs, res_hs; int32_t ld_res;
   const float* res2; int64_t res2_bs; int32_t ld_res2;  /* second additive residual (HiFi-GAN stage sum) */
   float* out; int64_t out_bs, out_hs; int32_t ld_out;
   int32_t precision;  /* SRN_PREC_* */

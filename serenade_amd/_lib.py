@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libserenade_hip.so")
 SRN_MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_AXPY = 0, 1, 2
-POST_NONE, POST_DIV, POST_TANH = 0, 1, 2
+POST_NONE, POST_DIV, POST_TANH, POST_RELU = 0, 1, 2, 3
 PREC_FP32, PREC_BF16X3 = 0, 1
 
 
@@ -29,7 +29,7 @@ class SrnConvParams(ctypes.Structure):
         ("in1", c_void_p), ("in1_bs", c_int64), ("ld_in1", c_int32),
         ("w", c_void_p), ("w_bs", c_int64), ("w_hs", c_int64), ("ldw", c_int32),
         ("bias", c_void_p), ("len_in", c_void_p), ("len_out", c_void_p),
-        ("res", c_void_p), ("res_bs", c_int64), ("ld_res", c_int32),
+        ("res", c_void_p), ("res_bs", c_int64), ("res_hs", c_int64), ("ld_res", c_int32),
         ("res2", c_void_p), ("res2_bs", c_int64), ("ld_res2", c_int32),
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ld_out", c_int32),
         ("precision", c_int32), ("gn_partials", c_void_p),

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
   // no __restrict__ here: res / res2 may alias out (in-place Euler update, HiFi-GAN stage sum)
   float* out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs;
-  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs : nullptr;
+  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs + (int64_t)zh * p.res_hs : nullptr;
   const float* res2 = p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
   int len_out = p.T_out;
   if (p.len_out) len_out = min(p.len_out[zb], p.T_out);
@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
           if (res2) v += res2[(int64_t)trow * p.ld_res2 + ocol];
           if (p.post == SRN_POST_DIV) v = v / p.post_div;
           else if (p.post == SRN_POST_TANH) v = tanhf(v);
+          else if (p.post == SRN_POST_RELU) v = fmaxf(v, 0.f);
           out[(int64_t)(trow * p.out_t_stride + p.out_t_off) * p.ld_out + ocol] = v;
           s1 += v;
           s2 += v * v;

@@ -630,7 +630,17 @@ class StyleEncoder(_Packed):
                 b = f"ref_enc.convs.{3 * i + 1}."
                 scale = sd[b + "weight"] / torch.sqrt(sd[b + "running_var"] + 1e-5)
                 shift = sd[b + "bias"] - sd[b + "running_mean"] * scale
-                P["convs"].append(dict(w=w, scale=scale.contiguous(), shift=shift.contiguous(), co=co))
+                # implicit-GEMM form: BatchNorm scale folded into the weights, one [Co][kw][Ci_pad] matrix per kh
+                ci = w.shape[3]
+                cpad = _rup(ci, 4)
+                wf = w * scale.view(-1, 1, 1, 1)
+                wk = []
+                for kh in range(3):
+                    m = wf.new_zeros(co, 3, cpad)
+                    m[:, :, :ci] = wf[:, kh]
+                    wk.append(m.reshape(co, 3 * cpad).contiguous())
+                P["convs"].append(dict(w=w, scale=scale.contiguous(), shift=shift.contiguous(), co=co, wk=wk,
+                                       cpad=cpad))
                 fdim = (fdim - 1) // 2 + 1
             C = self.chans[-1]
             wih = sd["ref_enc.gru.weight_ih_l0"]  # columns ordered (c, f) by the reference's view (:183-186)
@@ -650,12 +660,34 @@ class StyleEncoder(_Packed):
         P = self.packed()
         dev = self._device()
         ol = []
-        cur, H, W, Ci = speech, T, self.idim, 1
-        for c in P["convs"]:
-            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-            y = torch.zeros(B, Ho, Wo, c["co"], device=dev, dtype=torch.float32)
-            ol.append(ops.conv2d_bn_relu_op(cur, c["w"], c["scale"], c["shift"], y, B, H, W, Ci, c["co"]))
-            cur, H, W, Ci = y, Ho, Wo, c["co"]
+        # Conv2d(k3, s2, p1) + BN + ReLU as three implicit GEMMs per layer (one per kernel row kh): for a fixed
+        # kh the op is a stride-2, 3-tap conv along W over input row 2*ho + kh - 1, batched over (b, ho).
+        # Every layer input lives in a buffer with one zero row above and below (so kh = 0 / 2 never leave it);
+        # the kh = 1 launch initialises the output (+ folded BN shift), kh = 0 accumulates, kh = 2 accumulates
+        # and applies the ReLU.  [The direct kernel srn_conv2d_bn_relu stays in the ABI; this is ~10x faster.]
+        H, W, Ci = T, self.idim, 1
+        c0 = P["convs"][0]["cpad"]
+        cur = torch.zeros(B, H + 2, W, c0, device=dev, dtype=torch.float32)
+        ol.append(ops.copy_channels_op(speech, T * W, 1, 0, (cur, W * c0), (H + 2) * W * c0, c0, 0, B, T * W, 1))
+        n_l = len(P["convs"])
+        for li, c in enumerate(P["convs"]):
+            Ho, Wo, Co, Cp = (H - 1) // 2 + 1, (W - 1) // 2 + 1, c["co"], c["cpad"]
+            last = li == n_l - 1
+            pad = 0 if last else 1  # the last layer feeds the GRU: plain (B, Ho, Wo*Co)
+            y = torch.zeros(B, Ho + 2 * pad, Wo, Co, device=dev, dtype=torch.float32)
+            yo = (y, pad * Wo * Co)
+            for j, kh in enumerate((1, 0, 2)):
+                kw = dict(in0=(cur, kh * W * Cp), w=c["wk"][kh], out=yo, n_batch=B, n_head=Ho, T_in=W, T_out=Wo,
+                          C_in=Cp, N=Co, in0_bs=(H + 2) * W * Cp, in0_hs=2 * W * Cp, ld_in0=Cp, ldw=3 * Cp,
+                          out_bs=(Ho + 2 * pad) * Wo * Co, out_hs=Wo * Co, ld_out=Co, taps=[-1, 0, 1], in_stride=2)
+                if j == 0:
+                    kw.update(bias=c["shift"])
+                else:
+                    kw.update(res=yo, res_mode=RES_ADD, res_bs=(Ho + 2 * pad) * Wo * Co, res_hs=Wo * Co, ld_res=Co)
+                if j == 2:
+                    kw.update(post=ops.POST_RELU)
+                ol.append(ConvOp(**kw))
+            cur, H, W, Ci = y, Ho, Wo, Co
         ref = torch.zeros(B, self.gru_units, device=dev, dtype=torch.float32)
         ol.append(ops.gru_last_op(cur, P["w_ih"], P["w_hh"], P["b_ih"], P["b_hh"], ref, B, H, W * Ci, self.gru_units))
         ol.append(ops.style_token_attention_op(ref, P["embs"], P["wq"], P["bq"], P["wk"], P["bk"], P["wv"], P["bv"],

@@ -9,8 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_NONE, POST_TANH, RES_ADD,  # noqa: F401
-                   RES_AXPY, RES_NONE, SrnConvParams, check)
+from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
+                   RES_ADD, RES_AXPY, RES_NONE, SrnConvParams, check)
 
 
 DEFAULT_PRECISION = _lib.PREC_FP32  # contraction arithmetic of ops built without an explicit precision
@@ -48,7 +48,7 @@ class ConvOp:
     def _build(self, *, in0, w, out, n_batch, T_in, T_out, C_in, N, ld_in0, ldw, ld_out, taps=(0,), n_head=1,
                  in0_bs=0, in0_hs=0, in1=None, C_in0=0, in1_bs=0, ld_in1=0, C_w=0, w_bs=0, w_hs=0, w_nmajor=False,
                  bias=None, len_in=None, len_out=None, in_stride=1, reflect=False, pro_act=ACT_NONE, pro_slope=0.0,
-                 alpha=1.0, beta=0.0, geglu=False, res=None, res_mode=RES_NONE, res_bs=0, ld_res=0, res2=None,
+                 alpha=1.0, beta=0.0, geglu=False, res=None, res_mode=RES_NONE, res_bs=0, res_hs=0, ld_res=0, res2=None,
                  res2_bs=0, ld_res2=0, post=POST_NONE, post_div=1.0, out_bs=0, out_hs=0, out_t_stride=1, out_t_off=0,
                  gn_partials=None, N_out=0, tile=0, precision=None):
         p = SrnConvParams()
@@ -67,7 +67,7 @@ class ConvOp:
         p.in1, p.in1_bs, p.ld_in1 = _ptr(in1), int(in1_bs), int(ld_in1)
         p.w, p.w_bs, p.w_hs, p.ldw = _ptr(w), int(w_bs), int(w_hs), int(ldw)
         p.bias, p.len_in, p.len_out = _ptr(bias), _ptr(len_in), _ptr(len_out)
-        p.res, p.res_bs, p.ld_res = _ptr(res), int(res_bs), int(ld_res)
+        p.res, p.res_bs, p.res_hs, p.ld_res = _ptr(res), int(res_bs), int(res_hs), int(ld_res)
         p.res2, p.res2_bs, p.ld_res2 = _ptr(res2), int(res2_bs), int(ld_res2)
         p.out, p.out_bs, p.out_hs, p.ld_out = _ptr(out), int(out_bs), int(out_hs), int(ld_out)
         p.gn_partials = _ptr(gn_partials)

@@ -98,7 +98,7 @@ def emul_conv(kw):
             val[lo:] = 0
             cols = torch.arange(N_out).unsqueeze(0)
             if g("res_mode", 0):
-                ridx = o_res + zb * g("res_bs", 0) + t.unsqueeze(1) * g("ld_res") + cols
+                ridx = o_res + zb * g("res_bs", 0) + zh * g("res_hs", 0) + t.unsqueeze(1) * g("ld_res") + cols
                 if g("res_mode") == _lib.RES_ADD:
                     val = val + res[ridx]
                 else:
@@ -109,6 +109,8 @@ def emul_conv(kw):
                 val = val / g("post_div", 1.0)
             elif g("post", 0) == _lib.POST_TANH:
                 val = torch.tanh(val)
+            elif g("post", 0) == _lib.POST_RELU:
+                val = torch.relu(val)
             oidx = o_out + zb * g("out_bs", 0) + zh * g("out_hs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_out") + cols
             out[oidx] = val
             if gnp is not None:
