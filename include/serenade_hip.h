@@ -88,6 +88,7 @@ typedef struct SrnConvParams {
   const float* res2; int64_t res2_bs; int32_t ld_res2;  /* second additive residual (HiFi-GAN stage sum) */
   float* out; int64_t out_bs, out_hs; int32_t ld_out;
   int32_t precision;  /* SRN_PREC_* */
+  int32_t no_halo;    /* receptive-field (halo) kernel variant: 0 = automatic, 1 = never, 2 = whenever eligible (testing / A-B timing) */
   float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */
 } SrnConvParams;
 

@@ -1,0 +1,132 @@
+// conv_common.h — pieces shared by the implicit-GEMM kernels (conv_gemm.hip, conv_halo.hip): fragment types,
+// the fp32 -> (hi, lo) bf16 split, the swizzled bf16 LDS image, the XCD-aware block map and the fused epilogue.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// component-wise select (a float4 ?: is lowered through scratch memory by hipcc)
+__device__ __forceinline__ float4 sel4(unsigned ok, const float4& v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+__device__ __forceinline__ float4 leaky4(float4 v, float slope) {
+  v.x = v.x > 0.f ? v.x : v.x * slope;
+  v.y = v.y > 0.f ? v.y : v.y * slope;
+  v.z = v.z > 0.f ? v.z : v.z * slope;
+  v.w = v.w > 0.f ? v.w : v.w * slope;
+  return v;
+}
+
+// fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to 2^-17 relative (round-to-nearest twice; hipcc emits
+// v_cvt_pk_bf16_f32 + shift/and + v_sub: 3 VALU ops per element)
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x;
+  hi[1] = (__bf16)v.y;
+  hi[2] = (__bf16)v.z;
+  hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// byte offset of bf16 element (row, k) in a [rows][32] bf16 tile with 64-B rows whose four 16-B chunks are
+// XOR-swizzled by (row >> 2) & 3: ds_read_b128 of 16 different rows at one logical chunk is conflict-free
+__device__ __forceinline__ int bf_off(int row, int k) {
+  return row * 64 + ((((k >> 3) ^ (row >> 2)) & 3) << 4) + ((k & 7) << 1);
+}
+
+// XCD-aware, bijective blockIdx -> logical tile id (blocks b, b+8, ... share an XCD's L2): consecutive logical
+// ids (which share the A tile / neighbouring weight tiles) are dealt to one XCD.
+__device__ __forceinline__ int xcd_logical_block() {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Fused epilogue of one wave's MT x NT accumulator tiles (C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): alpha, bias, GEGLU gate, output mask, residual add / axpy,
+// second residual, post op, strided store, GroupNorm partial sums.
+// No __restrict__: res / res2 may alias out (in-place Euler update, HiFi-GAN stage sum).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&acc)[MT][NT], const int zb,
+                                              const int zh, const int t0, const int n0, const int wm0,
+                                              const int wn0, const int lane) {
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  float* out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs;
+  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs + (int64_t)zh * p.res_hs : nullptr;
+  const float* res2 = p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
+  int len_out = p.T_out;
+  if (p.len_out) len_out = min(p.len_out[zb], p.T_out);
+  const int gn_mt = (p.T_out + 31) / 32;
+  const int gn_nt = p.N / 32;
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (p.geglu && (n & 1)) continue;  // gate tiles are consumed with their value tile
+      const int ncol = n0 + wn0 + n * 32 + li;  // GEMM column
+      int ocol = ncol;
+      float bias_v = 0.f, bias_g = 0.f;
+      bool col_ok = ncol < p.N;
+      if (p.geglu) {
+        ocol = ((n0 + wn0 + n * 32) >> 6) * 32 + li;
+        if (p.bias && col_ok) {
+          bias_v = p.bias[ncol];
+          bias_g = p.bias[ncol + 32];
+        }
+      } else if (p.bias && col_ok) {
+        bias_v = p.bias[ncol];
+      }
+      col_ok = col_ok && ocol < p.N_out;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = t0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = col_ok && trow < p.T_out;
+        float v = acc[m][n][r] * p.alpha + bias_v;
+        if constexpr (NT % 2 == 0) {
+          if (p.geglu) {
+            const float g = acc[m][(n + 1) % NT][r] * p.alpha + bias_g;
+            v = v * srn_gelu_erf(g);
+          }
+        }
+        if (trow >= len_out) v = 0.f;
+        if (ok) {
+          if (p.res_mode == SRN_RES_ADD) {
+            v += res[(int64_t)trow * p.ld_res + ocol];
+          } else if (p.res_mode == SRN_RES_AXPY) {
+            v = res[(int64_t)trow * p.ld_res + ocol] + p.beta * v;
+          }
+          if (res2) v += res2[(int64_t)trow * p.ld_res2 + ocol];
+          if (p.post == SRN_POST_DIV) v = v / p.post_div;
+          else if (p.post == SRN_POST_TANH) v = tanhf(v);
+          else if (p.post == SRN_POST_RELU) v = fmaxf(v, 0.f);
+          out[(int64_t)(trow * p.out_t_stride + p.out_t_off) * p.ld_out + ocol] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (p.gn_partials) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const int gmt = (t0 + wm0 + m * 32) >> 5;
+        const int gnt = (n0 + wn0 + n * 32) >> 5;
+        if (lane == 0 && gmt < gn_mt && gnt < gn_nt) {
+          float* gp = p.gn_partials + (((int64_t)zb * gn_mt + gmt) * gn_nt + gnt) * 2;
+          gp[0] = s1;
+          gp[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+// implemented in conv_halo.hip: receptive-field ("halo") variant for stride-1 multi-tap convs in split-bf16.
+// Returns 1 if it handled the launch, 0 if the shape is not eligible, < 0 on error.
+int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);

@@ -14,11 +14,7 @@
 // The blockIdx -> tile map is XCD-aware (blocks that share an A tile land on one XCD's L2).
 //
 // Reference code this replaces: see include/serenade_hip.h (SrnConvParams).
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#include "conv_common.h"
 
 namespace {
 
@@ -50,30 +46,6 @@ __device__ __forceinline__ float4 act4(float4 v, int act, float slope) {
   return v;
 }
 
-// component-wise select (a float4 ?: is lowered through scratch memory by hipcc)
-__device__ __forceinline__ float4 sel4(unsigned ok, const float4& v) {
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
-// fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to 2^-17 relative (round-to-nearest twice; hipcc emits
-// v_cvt_pk_bf16_f32 + shift/and + v_sub: 3 VALU ops per element)
-__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
-  hi[0] = (__bf16)v.x;
-  hi[1] = (__bf16)v.y;
-  hi[2] = (__bf16)v.z;
-  hi[3] = (__bf16)v.w;
-  lo[0] = (__bf16)(v.x - (float)hi[0]);
-  lo[1] = (__bf16)(v.y - (float)hi[1]);
-  lo[2] = (__bf16)(v.z - (float)hi[2]);
-  lo[3] = (__bf16)(v.w - (float)hi[3]);
-}
-
-// byte offset of bf16 element (row, k) in a [rows][32] bf16 tile with 64-B rows whose four 16-B chunks are
-// XOR-swizzled by (row >> 2) & 3: ds_read_b128 of 16 different rows at one logical chunk is conflict-free
-__device__ __forceinline__ int bf_off(int row, int k) {
-  return row * 64 + ((((k >> 3) ^ (row >> 2)) & 3) << 4) + ((k & 7) << 1);
-}
-
 // ACT: prologue activation compiled in: SRN_ACT_NONE, SRN_ACT_LEAKY, or -1 = decided at run time (SiLU / Mish:
 // only the tiny time-embedding GEMMs use those, so only the small tile is instantiated with -1).
 // PREC: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = split-bf16: every fp32 operand is staged in LDS as a
@@ -94,13 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  // XCD-aware, bijective blockIdx -> logical tile id (blocks b, b+8, ... share an XCD).
-  int logical;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
+  const int logical = xcd_logical_block();
   const int nt_i = logical % n_tiles;
   const int rest = logical / n_tiles;
   const int mt_i = rest % m_tiles;
@@ -437,76 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
     }
   }
 
-  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  // no __restrict__ here: res / res2 may alias out (in-place Euler update, HiFi-GAN stage sum)
-  float* out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs;
-  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs + (int64_t)zh * p.res_hs : nullptr;
-  const float* res2 = p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
-  int len_out = p.T_out;
-  if (p.len_out) len_out = min(p.len_out[zb], p.T_out);
-  const int gn_mt = (p.T_out + 31) / 32;
-  const int gn_nt = p.N / 32;
-
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      if (p.geglu && (n & 1)) continue;  // gate tiles are consumed with their value tile
-      const int ncol = n0 + wn0 + n * 32 + li;  // GEMM column
-      int ocol = ncol;
-      float bias_v = 0.f, bias_g = 0.f;
-      bool col_ok = ncol < p.N;
-      if (p.geglu) {
-        ocol = ((n0 + wn0 + n * 32) >> 6) * 32 + li;
-        if (p.bias && col_ok) {
-          bias_v = p.bias[ncol];
-          bias_g = p.bias[ncol + 32];
-        }
-      } else if (p.bias && col_ok) {
-        bias_v = p.bias[ncol];
-      }
-      col_ok = col_ok && ocol < p.N_out;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int trow = t0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = col_ok && trow < p.T_out;
-        float v = acc[m][n][r] * p.alpha + bias_v;
-        if constexpr (NT % 2 == 0) {
-          if (p.geglu) {
-            const float g = acc[m][(n + 1) % NT][r] * p.alpha + bias_g;
-            v = v * srn_gelu_erf(g);
-          }
-        }
-        if (trow >= len_out) v = 0.f;
-        if (ok) {
-          if (p.res_mode == SRN_RES_ADD) {
-            v += res[(int64_t)trow * p.ld_res + ocol];
-          } else if (p.res_mode == SRN_RES_AXPY) {
-            v = res[(int64_t)trow * p.ld_res + ocol] + p.beta * v;
-          }
-          if (res2) v += res2[(int64_t)trow * p.ld_res2 + ocol];
-          if (p.post == SRN_POST_DIV) v = v / p.post_div;
-          else if (p.post == SRN_POST_TANH) v = tanhf(v);
-          else if (p.post == SRN_POST_RELU) v = fmaxf(v, 0.f);
-          out[(int64_t)(trow * p.out_t_stride + p.out_t_off) * p.ld_out + ocol] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-      if (p.gn_partials) {
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        const int gmt = (t0 + wm0 + m * 32) >> 5;
-        const int gnt = (n0 + wn0 + n * 32) >> 5;
-        if (lane == 0 && gmt < gn_mt && gnt < gn_nt) {
-          float* gp = p.gn_partials + (((int64_t)zb * gn_mt + gmt) * gn_nt + gnt) * 2;
-          gp[0] = s1;
-          gp[1] = s2;
-        }
-      }
-    }
-  }
+  conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
 }
 
 struct TileInfo {
@@ -616,6 +513,11 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
 
   int tile = p.tile > 0 ? p.tile : pick_tile(p);
   if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
+  if (p.no_halo != 1) {
+    // stride-1 multi-tap convs in split-bf16: stage the receptive-field tile once per channel chunk
+    const int r = srn_conv_halo_try(p, tile, stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   if (p.w_nmajor) {
     switch (tile) {
       case 1: return launch<Cfg<128, 128, 64, 64, true>>(p, stream);
