@@ -34,7 +34,8 @@ enum { SRN_RES_NONE = 0, SRN_RES_ADD = 1, SRN_RES_AXPY = 2 };
 /* post op */
 /* arithmetic of the contraction */
 enum { SRN_PREC_FP32 = 0 /* exact fp32 MFMA */, SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */ };
-enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2, SRN_POST_RELU = 3 };
+enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2, SRN_POST_RELU = 3,
+       SRN_POST_LEAKY = 4 /* LeakyReLU with slope post_div */ };
 
 /*
  * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors, computed with the exact-fp32
@@ -147,6 +148,11 @@ int srn_renorm(const float* x, const float* trg_scale, const float* trg_mean, co
  * x (B, T, C) channels-last, w (k, C), y (B, T). */
 int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int k,
                       float slope, void* stream);
+
+/* SiFiGAN pitch-dependent dilated-conv operand gather (row a9; un-vendored `sifigan` package, parity unpinned):
+ * out (B, T, 3C) = [lrelu(x[t]) | lrelu(x[t - r]) | lrelu(x[t + r])], r = rint(d[b, t] * dilation), zero outside. */
+int srn_pd_gather(const float* x, const float* d, float* out, int B, int T, int C, float dilation, float slope,
+                  void* stream);
 
 /* GST reference encoder layer: Conv2d(k3, s2, p1, no bias) + BatchNorm2d(eval) + ReLU (style_encoder.py:142-154),
  * NHWC: x (B, H, W, Ci) -> y (B, Ho, Wo, Co); w (Co, 3, 3, Ci); bn_scale/bn_shift (Co) = folded running stats. */

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libserenade_hip.so")
 SRN_MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_AXPY = 0, 1, 2
-POST_NONE, POST_DIV, POST_TANH, POST_RELU = 0, 1, 2, 3
+POST_NONE, POST_DIV, POST_TANH, POST_RELU, POST_LEAKY = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16X3 = 0, 1
 
 
@@ -51,6 +51,7 @@ _SIGS = {
     "srn_transpose_ct": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, _P]),
     "srn_renorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "srn_out_conv_tanh": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "srn_pd_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "srn_conv2d_bn_relu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_gru_last": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "srn_style_token_attention": (c_int, [_P] * 11 + [c_int] * 6 + [_P]),

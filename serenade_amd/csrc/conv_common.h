@@ -98,16 +98,18 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
         }
         if (trow >= len_out) v = 0.f;
         if (ok) {
+          const int64_t orow = (int64_t)trow * p.out_t_stride + p.out_t_off;  // residuals are indexed like `out`
           if (p.res_mode == SRN_RES_ADD) {
-            v += res[(int64_t)trow * p.ld_res + ocol];
+            v += res[orow * p.ld_res + ocol];
           } else if (p.res_mode == SRN_RES_AXPY) {
-            v = res[(int64_t)trow * p.ld_res + ocol] + p.beta * v;
+            v = res[orow * p.ld_res + ocol] + p.beta * v;
           }
-          if (res2) v += res2[(int64_t)trow * p.ld_res2 + ocol];
+          if (res2) v += res2[orow * p.ld_res2 + ocol];
           if (p.post == SRN_POST_DIV) v = v / p.post_div;
           else if (p.post == SRN_POST_TANH) v = tanhf(v);
           else if (p.post == SRN_POST_RELU) v = fmaxf(v, 0.f);
-          out[(int64_t)(trow * p.out_t_stride + p.out_t_off) * p.ld_out + ocol] = v;
+          else if (p.post == SRN_POST_LEAKY) v = v > 0.f ? v : v * p.post_div;
+          out[orow * p.ld_out + ocol] = v;
           s1 += v;
           s2 += v * v;
         }

@@ -494,3 +494,52 @@ extern "C" int srn_out_conv_tanh(const float* x, const float* w, const float* bi
   SRN_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// SiFiGAN "pitch-dependent dilated conv" operand gather (row a9, parity unpinned: see oracle/sifigan_oracle.py):
+//   out[b, t, 0:C]   = lrelu(x[b, t])
+//   out[b, t, C:2C]  = lrelu(x[b, t - r]),  out[b, t, 2C:3C] = lrelu(x[b, t + r]),   r = rint(d[b, t] * dilation)
+// (zero outside the signal).  Whole 128-B+ channel rows move as float4; one wave handles several rows.
+namespace {
+__global__ __launch_bounds__(256) void pd_gather_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                        float* __restrict__ out, int T, int C, float dilation,
+                                                        float slope) {
+  const int b = blockIdx.y;
+  const int c4n = C / 4;
+  const int64_t total = (int64_t)T * c4n;
+  const float* xb = x + (int64_t)b * T * C;
+  float* ob = out + (int64_t)b * T * 3 * C;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int t = (int)(idx / c4n);
+    const int c = (int)(idx - (int64_t)t * c4n) * 4;
+    const int r = (int)rintf(d[(int64_t)b * T + t] * dilation);
+    const int tp = t - r, tf = t + r;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v0 = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + c);
+    float4 vp = (tp >= 0 && tp < T) ? *reinterpret_cast<const float4*>(xb + (int64_t)tp * C + c) : z;
+    float4 vf = (tf >= 0 && tf < T) ? *reinterpret_cast<const float4*>(xb + (int64_t)tf * C + c) : z;
+    auto lr = [slope](float4 v) {
+      v.x = v.x > 0.f ? v.x : v.x * slope;
+      v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope;
+      v.w = v.w > 0.f ? v.w : v.w * slope;
+      return v;
+    };
+    float* o = ob + (int64_t)t * 3 * C + c;
+    *reinterpret_cast<float4*>(o) = lr(v0);
+    *reinterpret_cast<float4*>(o + C) = lr(vp);
+    *reinterpret_cast<float4*>(o + 2 * C) = lr(vf);
+  }
+}
+}  // namespace
+
+extern "C" int srn_pd_gather(const float* x, const float* d, float* out, int B, int T, int C, float dilation,
+                             float slope, void* stream) {
+  SRN_CHECK_ARG(x && d && out && B > 0 && T > 0 && C > 0 && C % 4 == 0, "pd_gather: bad args");
+  int64_t blocks = ((int64_t)T * (C / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pd_gather_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, x, d, out, T, C,
+                     dilation, slope);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}

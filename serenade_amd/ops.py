@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_NONE, POST_RELU, POST_TANH,  # noqa: F401
+from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_LEAKY, POST_NONE, POST_RELU,  # noqa: F401
+                   POST_TANH,
                    RES_ADD, RES_AXPY, RES_NONE, SrnConvParams, check)
 
 
@@ -142,6 +143,10 @@ def renorm_op(x, trg_scale, trg_mean, voc_mean, voc_scale, y, rows, C):
 
 def out_conv_tanh_op(x, w, bias, y, B, T, C, k, slope):
     return CallOp("srn_out_conv_tanh", (x, w, bias, y, B, T, C, k, slope))
+
+
+def pd_gather_op(x, d, out, B, T, C, dilation, slope):
+    return CallOp("srn_pd_gather", (x, d, out, B, T, C, float(dilation), float(slope)))
 
 
 def conv2d_bn_relu_op(x, w, bn_scale, bn_shift, y, B, H, W, Ci, Co):

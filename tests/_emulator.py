@@ -98,19 +98,21 @@ def emul_conv(kw):
             val[lo:] = 0
             cols = torch.arange(N_out).unsqueeze(0)
             if g("res_mode", 0):
-                ridx = o_res + zb * g("res_bs", 0) + zh * g("res_hs", 0) + t.unsqueeze(1) * g("ld_res") + cols
+                ridx = o_res + zb * g("res_bs", 0) + zh * g("res_hs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_res") + cols
                 if g("res_mode") == _lib.RES_ADD:
                     val = val + res[ridx]
                 else:
                     val = res[ridx] + g("beta", 0.0) * val
             if res2 is not None:
-                val = val + res2[o_res2 + zb * g("res2_bs", 0) + t.unsqueeze(1) * g("ld_res2") + cols]
+                val = val + res2[o_res2 + zb * g("res2_bs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_res2") + cols]
             if g("post", 0) == _lib.POST_DIV:
                 val = val / g("post_div", 1.0)
             elif g("post", 0) == _lib.POST_TANH:
                 val = torch.tanh(val)
             elif g("post", 0) == _lib.POST_RELU:
                 val = torch.relu(val)
+            elif g("post", 0) == _lib.POST_LEAKY:
+                val = F.leaky_relu(val, g("post_div", 1.0))
             oidx = o_out + zb * g("out_bs", 0) + zh * g("out_hs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_out") + cols
             out[oidx] = val
             if gnp is not None:
@@ -211,6 +213,16 @@ def emul_call(name, a):
         xv = F.leaky_relu(_v(x, B * T * C).reshape(B, T, C), slope).transpose(1, 2)
         wv = _v(w, k * C).reshape(k, C).t().unsqueeze(0)
         _v(y, B * T).reshape(B, T)[:] = torch.tanh(F.conv1d(xv, wv, bias.view(-1), padding=(k - 1) // 2))[:, 0]
+    elif name == "srn_pd_gather":
+        x, d, out, B, T, C, dil, slope = a
+        xv = F.leaky_relu(_v(x, B * T * C).reshape(B, T, C), slope)
+        r = torch.round(_v(d, B * T).reshape(B, T) * dil).long()
+        t = torch.arange(T).unsqueeze(0)
+        ov = _v(out, B * T * 3 * C).reshape(B, T, 3 * C)
+        ov[:, :, :C] = xv
+        for k, idx in ((1, t - r), (2, t + r)):
+            ok = ((idx >= 0) & (idx < T)).unsqueeze(-1)
+            ov[:, :, k * C:(k + 1) * C] = torch.gather(xv, 1, idx.clamp(0, T - 1).unsqueeze(-1).expand(B, T, C)) * ok
     elif name == "srn_conv2d_bn_relu":
         x, w, sc, sh, y, B, H, W, Ci, Co = a
         xv = _v(x, B * H * W * Ci).reshape(B, H, W, Ci).permute(0, 3, 1, 2)
@@ -245,12 +257,16 @@ class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
     def __enter__(self):
-        self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, models._require_cuda, vocoder._require_cuda)
+        from serenade_amd import sifigan
+        self._mods = (models, vocoder, sifigan)
+        self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods])
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)
         ops.CallOp.__call__ = lambda self_, stream=None: emul_call(self_.name, self_.targs)
-        models._require_cuda = lambda *a, **k: None
-        vocoder._require_cuda = lambda *a, **k: None
+        for m in self._mods:
+            m._require_cuda = lambda *a, **k: None
         return self
 
     def __exit__(self, *exc):
-        ops.ConvOp.__call__, ops.CallOp.__call__, models._require_cuda, vocoder._require_cuda = self._saved
+        ops.ConvOp.__call__, ops.CallOp.__call__, guards = self._saved
+        for m, g in zip(self._mods, guards):
+            m._require_cuda = g
