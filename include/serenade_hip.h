@@ -90,6 +90,12 @@ typedef struct SrnConvParams {
   float* out; int64_t out_bs, out_hs; int32_t ld_out;
   int32_t precision;  /* SRN_PREC_* */
   int32_t no_halo;    /* receptive-field (halo) kernel variant: 0 = automatic, 1 = never, 2 = whenever eligible (testing / A-B timing) */
+  /* split-bf16 fast path (conv_planes.hip): an HBM workspace into which the operands are split once into (hi, lo)
+   * bf16 planes and from which the GEMM streams them with LDS-DMA.  ws == NULL selects the in-kernel split path.
+   * w_hi: weights already split at load time, bf16 [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32] (NULL: split per
+   * call; w_lo is reserved). */
+  void* ws; int64_t ws_bytes;
+  const void* w_hi; const void* w_lo;
   float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */
 } SrnConvParams;
 

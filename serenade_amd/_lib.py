@@ -32,7 +32,8 @@ class SrnConvParams(ctypes.Structure):
         ("res", c_void_p), ("res_bs", c_int64), ("res_hs", c_int64), ("ld_res", c_int32),
         ("res2", c_void_p), ("res2_bs", c_int64), ("ld_res2", c_int32),
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ld_out", c_int32),
-        ("precision", c_int32), ("no_halo", c_int32), ("gn_partials", c_void_p),
+        ("precision", c_int32), ("no_halo", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64),
+        ("w_hi", c_void_p), ("w_lo", c_void_p), ("gn_partials", c_void_p),
     ]
 
 

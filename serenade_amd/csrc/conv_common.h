@@ -47,6 +47,23 @@ __device__ __forceinline__ int xcd_logical_block() {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// logical tile id -> (z, m tile, n tile). Inside one z the tiles are walked in bands of TILE_BAND m-tiles, m
+// fastest: the ~64 blocks resident on one XCD then cover an 8 x 8 patch (16 operand panels for 64 tiles) instead
+// of one m-tile row x all n-tiles (n_tiles + 1 panels), which is what keeps wide-N weights inside the 4 MB L2.
+constexpr int TILE_BAND = 8;
+__device__ __forceinline__ void tile_coords(const int logical, const int m_tiles, const int n_tiles, int& z,
+                                            int& mt_i, int& nt_i) {
+  const int per_z = m_tiles * n_tiles;
+  z = logical / per_z;
+  const int l = logical - z * per_z;
+  const int band = l / (TILE_BAND * n_tiles);
+  const int m0 = band * TILE_BAND;
+  const int gm = min(TILE_BAND, m_tiles - m0);
+  const int r = l - band * TILE_BAND * n_tiles;
+  nt_i = r / gm;
+  mt_i = m0 + (r - nt_i * gm);
+}
+
 // Fused epilogue of one wave's MT x NT accumulator tiles (C/D map of the 32x32 MFMA: col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): alpha, bias, GEGLU gate, output mask, residual add / axpy,
 // second residual, post op, strided store, GroupNorm partial sums.
@@ -132,3 +149,5 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
 // implemented in conv_halo.hip: receptive-field ("halo") variant for stride-1 multi-tap convs in split-bf16.
 // Returns 1 if it handled the launch, 0 if the shape is not eligible, < 0 on error.
 int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);
+// implemented in conv_planes.hip: operands pre-split into bf16 planes in p.ws, LDS-DMA pipeline.  Same return codes.
+int srn_conv_planes_try(const SrnConvParams& p, int tile, hipStream_t stream);

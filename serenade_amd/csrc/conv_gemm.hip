@@ -67,10 +67,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   const int wave = tid >> 6;
 
   const int logical = xcd_logical_block();
-  const int nt_i = logical % n_tiles;
-  const int rest = logical / n_tiles;
-  const int mt_i = rest % m_tiles;
-  const int z = rest / m_tiles;
+  int z, mt_i, nt_i;
+  tile_coords(logical, m_tiles, n_tiles, z, mt_i, nt_i);
   const int zb = z / p.n_head;
   const int zh = z - zb * p.n_head;
   const int t0 = mt_i * BM;
@@ -513,6 +511,10 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
 
   int tile = p.tile > 0 ? p.tile : pick_tile(p);
   if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
+  if (p.ws != nullptr) {
+    const int r = srn_conv_planes_try(p, tile, stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   if (p.no_halo != 1) {
     // stride-1 multi-tap convs in split-bf16: stage the receptive-field tile once per channel chunk
     const int r = srn_conv_halo_try(p, tile, stream);

@@ -46,10 +46,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const SrnConvParams p
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int logical = xcd_logical_block();
-  const int nt_i = logical % n_tiles;
-  const int rest = logical / n_tiles;
-  const int mt_i = rest % m_tiles;
-  const int z = rest / m_tiles;
+  int z, mt_i, nt_i;
+  tile_coords(logical, m_tiles, n_tiles, z, mt_i, nt_i);
   const int zb = z / p.n_head;
   const int zh = z - zb * p.n_head;
   const int t0 = mt_i * BM;

@@ -425,6 +425,7 @@ class DecoderPlan:
         if self.steps is None or self._dts != dts:
             self.steps = [self._build_step(k, dts[k]) for k in range(self.n)]
             self._dts = dts
+            ops.attach_workspace(self.pre + [op for ol in self.steps for op in ol], self.h0.device)
 
     def set_lens(self, lens):
         lens = torch.as_tensor(lens).to(torch.int64).cpu()
@@ -596,7 +597,9 @@ class Conv1dResnet(_Packed):
         B, T, _ = x.shape
         xin = x.detach().to(torch.float32).contiguous()
         out = torch.empty(B, T, self.out_dim, device=x.device, dtype=torch.float32)
-        for op in self.build_ops(xin, B, T, out, T * self.out_dim, self.out_dim):
+        ol = self.build_ops(xin, B, T, out, T * self.out_dim, self.out_dim)
+        ops.attach_workspace(ol, x.device)
+        for op in ol:
             op()
         return out
 
@@ -702,7 +705,9 @@ class StyleEncoder(_Packed):
         _require_cuda(speech, "StyleEncoder.forward")
         B, T, _ = speech.shape
         out = torch.empty(B, self.gst_token_dim, device=speech.device, dtype=torch.float32)
-        for op in self.build_ops(speech.detach().to(torch.float32).contiguous(), B, T, out):
+        ol = self.build_ops(speech.detach().to(torch.float32).contiguous(), B, T, out)
+        ops.attach_workspace(ol, speech.device)
+        for op in ol:
             op()
         return out
 
@@ -806,6 +811,7 @@ class Serenade(_Packed):
         pl.set_lens(total)
         pl._xin.copy_(z)
         pl.load_ops[0]()
+        ops.attach_workspace(ol, dev)
         for op in ol:
             op()
         pl.run()

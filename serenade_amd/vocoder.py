@@ -231,6 +231,7 @@ class HiFiGANPlan:
         ol.append(ops.out_conv_tanh_op(cur, P["out_w"], P["out_b"], self.wave, B, tcur, ccur, gen.kernel_size, 0.01))
         self.ops = ol
         self._keep = (h, u, p0, p1, xt, acc)
+        ops.attach_workspace(ol, dev)
 
     def run(self):
         for op in self.ops:

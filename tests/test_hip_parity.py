@@ -83,7 +83,8 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     """run the kernel (for each tile id) and the spec on clones of the same inputs; compare every buffer"""
     base = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
     tol = KTOL.k if tol is None else tol
-    for tile in tiles:
+    planes = (False, True) if serenade_amd.get_precision() == "bf16x3" else (False,)
+    for tile, use_ws in [(t, u) for t in tiles for u in planes]:
         cpu = {}
         memo = {}
 
@@ -101,13 +102,22 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
         m = Mirror(dev)
         gpu = {k: m(v) for k, v in cpu.items()}
         gpu["tile"] = tile
-        ops.ConvOp(**gpu)()
+        saved, ops.USE_PLANES = ops.USE_PLANES, use_ws
+        try:
+            op = ops.ConvOp(**gpu)
+        finally:
+            ops.USE_PLANES = saved
+        if use_ws:  # split-bf16 through pre-split planes + LDS-DMA pipeline (conv_planes.hip)
+            ops.attach_workspace([op], dev)
+            if not op.p.ws:
+                continue
+        op()
         torch.cuda.synchronize()
         _emulator.emul_conv(cpu)
         for c, g in m.pairs():
             if c.is_floating_point():
                 e = nerr(g, c)
-                assert e < tol, f"tile {tile}: mismatch {e}"
+                assert e < tol, f"tile {tile} planes {use_ws}: mismatch {e}"
     del base
 
 

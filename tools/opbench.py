@@ -87,6 +87,7 @@ def sweep(oplist, reps=5):
 def main():
     if "--no-halo" in sys.argv:
         ops.NO_HALO = True
+    ops.USE_PLANES = "--planes" in sys.argv
     if "--bf16x3" in sys.argv:
         from serenade_amd import _lib
         ops.DEFAULT_PRECISION = _lib.PREC_BF16X3
