@@ -32,10 +32,18 @@ enum { SRN_ACT_NONE = 0, SRN_ACT_LEAKY = 1, SRN_ACT_SILU = 2, SRN_ACT_MISH = 3 }
 /* residual mode */
 enum { SRN_RES_NONE = 0, SRN_RES_ADD = 1, SRN_RES_AXPY = 2 };
 /* post op */
+enum {
+  SRN_POST_NONE = 0,
+  SRN_POST_DIV = 1, /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */
+  SRN_POST_TANH = 2,
+  SRN_POST_RELU = 3,
+  SRN_POST_LEAKY = 4 /* LeakyReLU with slope post_div */
+};
 /* arithmetic of the contraction */
-enum { SRN_PREC_FP32 = 0 /* exact fp32 MFMA */, SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */ };
-enum { SRN_POST_NONE = 0, SRN_POST_DIV = 1 /* v / post_div (HiFi-GAN: cs / num_blocks, hifigan.py:186) */, SRN_POST_TANH = 2, SRN_POST_RELU = 3,
-       SRN_POST_LEAKY = 4 /* LeakyReLU with slope post_div */ };
+enum {
+  SRN_PREC_FP32 = 0,  /* exact fp32 MFMA */
+  SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */
+};
 
 /*
  * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors, computed with the exact-fp32
