@@ -68,65 +68,84 @@ __device__ __forceinline__ void tile_coords(const int logical, const int m_tiles
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): alpha, bias, GEGLU gate, output mask, residual add / axpy,
 // second residual, post op, strided store, GroupNorm partial sums.
 // No __restrict__: res / res2 may alias out (in-place Euler update, HiFi-GAN stage sum).
-template <int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&acc)[MT][NT], const int zb,
-                                              const int zh, const int t0, const int n0, const int wm0,
-                                              const int wn0, const int lane) {
+//
+// Addressing: every tensor is walked as  wave-uniform 64-bit base (SGPRs, advanced per accumulator row)  +  one
+// per-lane 32-bit element offset that does not depend on the row, so an element costs one store (and one load per
+// residual) plus scalar adds.  GEGLU / RES are compile-time: the common plain epilogue carries no residual or
+// post-op code, and interior 32x32 sub-tiles skip the bounds predicates.
+template <int MT, int NT, bool GEGLU, bool RES>
+__device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x16 (&acc)[MT][NT], const int zb,
+                                                   const int zh, const int t0, const int n0, const int wm0,
+                                                   const int wn0, const int lane) {
   const int li = lane & 31;
   const int lh = lane >> 5;
   float* out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs;
-  const float* res = p.res ? p.res + (int64_t)zb * p.res_bs + (int64_t)zh * p.res_hs : nullptr;
-  const float* res2 = p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
+  const float* res = RES && p.res ? p.res + (int64_t)zb * p.res_bs + (int64_t)zh * p.res_hs : nullptr;
+  const float* res2 = RES && p.res2 ? p.res2 + (int64_t)zb * p.res2_bs : nullptr;
   int len_out = p.T_out;
   if (p.len_out) len_out = min(p.len_out[zb], p.T_out);
   const int gn_mt = (p.T_out + 31) / 32;
   const int gn_nt = p.N / 32;
+  const int ts = p.out_t_stride;
+  const float alpha = p.alpha;
+  const int res_mode = RES ? p.res_mode : SRN_RES_NONE;
+  const int post = RES ? p.post : SRN_POST_NONE;
 
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
+    const int tm = t0 + wm0 + m * 32;  // wave-uniform first row of the sub-tile
+    if (tm >= p.T_out) continue;
+    const int64_t orow0 = (int64_t)tm * ts + p.out_t_off;
+    const bool rows_in = tm + 32 <= p.T_out;
+    const bool rows_live = tm + 32 <= len_out;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      if (p.geglu && (n & 1)) continue;  // gate tiles are consumed with their value tile
-      const int ncol = n0 + wn0 + n * 32 + li;  // GEMM column
-      int ocol = ncol;
+      if (GEGLU && (n & 1)) continue;  // gate tiles are consumed with their value tile
+      const int nc0 = n0 + wn0 + n * 32;  // wave-uniform first GEMM column
+      const int oc0 = GEGLU ? (nc0 >> 6) * 32 : nc0;
+      const int ncol = nc0 + li;
+      const int ocol = oc0 + li;
       float bias_v = 0.f, bias_g = 0.f;
       bool col_ok = ncol < p.N;
-      if (p.geglu) {
-        ocol = ((n0 + wn0 + n * 32) >> 6) * 32 + li;
-        if (p.bias && col_ok) {
-          bias_v = p.bias[ncol];
-          bias_g = p.bias[ncol + 32];
-        }
-      } else if (p.bias && col_ok) {
+      if (p.bias && col_ok) {
         bias_v = p.bias[ncol];
+        if (GEGLU) bias_g = p.bias[ncol + 32];
       }
       col_ok = col_ok && ocol < p.N_out;
+      const bool interior = rows_in && nc0 + 32 <= p.N && oc0 + 32 <= p.N_out;
+      // wave-uniform bases at sub-tile row 0 / column 0 and the per-lane, row-independent offsets
+      float* o_u = out + orow0 * p.ld_out + oc0;
+      const unsigned o_v = (unsigned)(4 * lh * ts) * (unsigned)p.ld_out + li;
+      const int64_t o_rs = (int64_t)ts * p.ld_out;
+      const float* r_u = res ? res + orow0 * p.ld_res + oc0 : nullptr;
+      const unsigned r_v = (unsigned)(4 * lh * ts) * (unsigned)p.ld_res + li;
+      const int64_t r_rs = (int64_t)ts * p.ld_res;
+      const float* q_u = res2 ? res2 + orow0 * p.ld_res2 + oc0 : nullptr;
+      const unsigned q_v = (unsigned)(4 * lh * ts) * (unsigned)p.ld_res2 + li;
+      const int64_t q_rs = (int64_t)ts * p.ld_res2;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int trow = t0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = col_ok && trow < p.T_out;
-        float v = acc[m][n][r] * p.alpha + bias_v;
-        if constexpr (NT % 2 == 0) {
-          if (p.geglu) {
-            const float g = acc[m][(n + 1) % NT][r] * p.alpha + bias_g;
-            v = v * srn_gelu_erf(g);
-          }
+        const int dr = (r & 3) + 8 * (r >> 2);  // compile-time row of this register (+ 4 lh per lane)
+        float v = acc[m][n][r] * alpha + bias_v;
+        if constexpr (GEGLU) {
+          const float g = acc[m][(n + 1) % NT][r] * alpha + bias_g;
+          v = v * srn_gelu_erf(g);
         }
-        if (trow >= len_out) v = 0.f;
+        const int trow = tm + dr + 4 * lh;
+        if (!rows_live && trow >= len_out) v = 0.f;
+        const bool ok = interior || (col_ok && trow < p.T_out);
         if (ok) {
-          const int64_t orow = (int64_t)trow * p.out_t_stride + p.out_t_off;  // residuals are indexed like `out`
-          if (p.res_mode == SRN_RES_ADD) {
-            v += res[orow * p.ld_res + ocol];
-          } else if (p.res_mode == SRN_RES_AXPY) {
-            v = res[orow * p.ld_res + ocol] + p.beta * v;
+          if constexpr (RES) {
+            if (res_mode == SRN_RES_ADD) v += (r_u + dr * r_rs)[r_v];
+            else if (res_mode == SRN_RES_AXPY) v = (r_u + dr * r_rs)[r_v] + p.beta * v;
+            if (q_u) v += (q_u + dr * q_rs)[q_v];
+            if (post == SRN_POST_DIV) v = v / p.post_div;
+            else if (post == SRN_POST_TANH) v = tanhf(v);
+            else if (post == SRN_POST_RELU) v = fmaxf(v, 0.f);
+            else if (post == SRN_POST_LEAKY) v = v > 0.f ? v : v * p.post_div;
           }
-          if (res2) v += res2[orow * p.ld_res2 + ocol];
-          if (p.post == SRN_POST_DIV) v = v / p.post_div;
-          else if (p.post == SRN_POST_TANH) v = tanhf(v);
-          else if (p.post == SRN_POST_RELU) v = fmaxf(v, 0.f);
-          else if (p.post == SRN_POST_LEAKY) v = v > 0.f ? v : v * p.post_div;
-          out[orow * p.ld_out + ocol] = v;
+          (o_u + dr * o_rs)[o_v] = v;
           s1 += v;
           s2 += v * v;
         }
@@ -134,8 +153,8 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
       if (p.gn_partials) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
-        const int gmt = (t0 + wm0 + m * 32) >> 5;
-        const int gnt = (n0 + wn0 + n * 32) >> 5;
+        const int gmt = tm >> 5;
+        const int gnt = nc0 >> 5;
         if (lane == 0 && gmt < gn_mt && gnt < gn_nt) {
           float* gp = p.gn_partials + (((int64_t)zb * gn_mt + gmt) * gn_nt + gnt) * 2;
           gp[0] = s1;
@@ -144,6 +163,24 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
       }
     }
   }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&acc)[MT][NT], const int zb,
+                                              const int zh, const int t0, const int n0, const int wm0_,
+                                              const int wn0_, const int lane) {
+  const int wm0 = __builtin_amdgcn_readfirstlane(wm0_);
+  const int wn0 = __builtin_amdgcn_readfirstlane(wn0_);
+  if constexpr (NT % 2 == 0) {
+    if (p.geglu) {
+      conv_epilogue_impl<MT, NT, true, false>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+      return;
+    }
+  }
+  if (p.res_mode == SRN_RES_NONE && p.res2 == nullptr && p.post == SRN_POST_NONE)
+    conv_epilogue_impl<MT, NT, false, false>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+  else
+    conv_epilogue_impl<MT, NT, false, true>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
 }
 
 // implemented in conv_halo.hip: receptive-field ("halo") variant for stride-1 multi-tap convs in split-bf16.

@@ -501,7 +501,9 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
   if (p.in_stride <= 0) p.in_stride = 1;
   if (p.out_t_stride <= 0) p.out_t_stride = 1;
   if (p.N_out <= 0) p.N_out = p.geglu ? p.N / 2 : p.N;
-  if (p.geglu) SRN_CHECK_ARG(p.N % 64 == 0, "conv_gemm: GEGLU needs N %% 64 == 0");
+  if (p.geglu)
+    SRN_CHECK_ARG(p.N % 64 == 0 && p.res_mode == SRN_RES_NONE && p.res2 == nullptr && p.post == SRN_POST_NONE,
+                  "conv_gemm: GEGLU needs N %% 64 == 0 and no residual / post op");
   if (p.res_mode != SRN_RES_NONE) SRN_CHECK_ARG(p.res != nullptr, "conv_gemm: res_mode set but res is null");
   if (p.gn_partials) SRN_CHECK_ARG(p.N % 32 == 0 && !p.geglu, "conv_gemm: gn_partials needs N %% 32 == 0");
   if (p.pad_reflect) {

@@ -19,7 +19,10 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int NSTAGE = 3;
+#ifndef SRN_PLANES_NSTAGE
+#define SRN_PLANES_NSTAGE 2
+#endif
+constexpr int NSTAGE = SRN_PLANES_NSTAGE;  // 3: prefetch distance 2 at 1 block/CU; 2: double buffer at 2 blocks/CU
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -118,7 +121,7 @@ struct PlaneArgs {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void conv_planes_kernel(const SrnConvParams p, const PlaneArgs q, const int m_tiles,
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_planes_kernel(const SrnConvParams p, const PlaneArgs q, const int m_tiles,
                                                           const int n_tiles) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
@@ -243,29 +246,41 @@ __global__ __launch_bounds__(256) void conv_planes_kernel(const SrnConvParams p,
     }
   };
 
-  // ---- pipeline (prefetch distance 2, three LDS stages)
-  issue(0, 0);
-  if (n_steps > 1) issue(1, 1);
-  int stage = 0;
-  for (int step = 0; step < n_steps; ++step) {
-    // own DMA(step) has landed once at most the PER instructions of DMA(step+1) are still outstanding
-    if (step + 1 < n_steps) {
-      if constexpr (C::PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (C::PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr (C::PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if constexpr (C::PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
+  // ---- pipeline
+  if constexpr (NSTAGE == 2) {
+    // double buffer: DMA(step+1) flies during compute(step); the co-resident block fills the wait
+    issue(0, 0);
+    for (int step = 0; step < n_steps; ++step) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's DMA(step) landed; everyone is done reading the other stage
+      if (step + 1 < n_steps) issue(step + 1, (step + 1) & 1);
+      compute(step & 1);
     }
-    __builtin_amdgcn_s_barrier();  // everyone's DMA(step) landed; everyone is done reading the stage of step-1
-    if (step + 2 < n_steps) {
-      int s2 = stage + 2;
-      if (s2 >= NSTAGE) s2 -= NSTAGE;
-      issue(step + 2, s2);
+  } else {
+    // prefetch distance 2, three LDS stages
+    issue(0, 0);
+    if (n_steps > 1) issue(1, 1);
+    int stage = 0;
+    for (int step = 0; step < n_steps; ++step) {
+      // own DMA(step) has landed once at most the PER instructions of DMA(step+1) are still outstanding
+      if (step + 1 < n_steps) {
+        if constexpr (C::PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (C::PER == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (C::PER == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (C::PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // everyone's DMA(step) landed; everyone is done reading the stage of step-1
+      if (step + 2 < n_steps) {
+        int s2 = stage + 2;
+        if (s2 >= NSTAGE) s2 -= NSTAGE;
+        issue(step + 2, s2);
+      }
+      compute(stage);
+      if (++stage == NSTAGE) stage = 0;
     }
-    compute(stage);
-    if (++stage == NSTAGE) stage = 0;
   }
 
   conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
