@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libserenade_hip.so")
+LIB_PATH = os.environ.get("SERENADE_AMD_LIB") or os.path.join(_HERE, "libserenade_hip.so")  # env: developer builds
 
 SRN_MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3

@@ -1,0 +1,341 @@
+// conv_fast.hip -- lean split-bf16 implicit-GEMM kernel for the regular shapes of the path
+// (C_in a multiple of 32, k-major weights): the same contraction, LDS image, MFMA sequence and epilogue as
+// conv_gemm.hip's split-bf16 path, with the per-step instruction count cut from ~420 to ~150 per wave:
+//   * measured (tools/ksweep.py on timing-only builds): the generic kernel is ISSUE-bound, not memory- or
+//     MFMA-bound -- all-L2-hit operands do not speed it up, removing the global loads' address arithmetic does;
+//   * operand cursors: per-lane row pointers are set up once per (tap, input tensor) and bumped by a constant
+//     per 32-channel step; padded / masked rows point at a zero page with bump 0 (no selects after the load);
+//   * static weights arrive pre-split (bf16 hi|lo planes, one 128-B line per row per 32-channel step, packed at
+//     load time by ops.weight_planes): 16-B loads go to LDS untouched, only activations are split in the loop;
+//   * the split itself is 2.5 VALU per element (v_cvt_pk_bf16_f32 on pairs, v_pk_add_f32).
+// Shapes it does not take (ragged channels, n-major B, fp32 mode) stay on conv_gemm.hip.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "conv_common.h"
+#include "serenade_hip.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+// 256 B of zeros: the source of every padded / masked operand row
+__device__ __attribute__((aligned(256))) float g_zero_page[64];
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo, both round-to-nearest bf16; 5 VALU per pair
+__device__ __forceinline__ void split_pair(const float a, const float b, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  f32x2 hf;
+  hf.x = __builtin_bit_cast(float, hi << 16);
+  hf.y = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const f32x2 l = v - hf;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+}
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct FCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int MT = WM / 32, NT = WN / 32;
+  static constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+  static constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per step
+  static constexpr int STAGE = (BM + BN) * 128;          // [A_hi | A_lo | B_hi | B_lo], 64 B per tile row
+  static constexpr int SMEM_BYTES = 2 * STAGE;
+};
+
+// ACT: SRN_ACT_NONE / SRN_ACT_LEAKY compile-time, -1 = run-time p.pro_act (SiLU / Mish).
+// WPL: B operand is the pre-split weight plane image (p.w_hi); otherwise fp32 rows split in the loop (Q K^T).
+template <class C, int ACT, bool WPL>
+__global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
+                                                           const int n_tiles) {
+  constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_logical_block();
+  int z, mt_i, nt_i;
+  tile_coords(logical, m_tiles, n_tiles, z, mt_i, nt_i);
+  const int zb = z / p.n_head;
+  const int zh = z - zb * p.n_head;
+  const int t0 = mt_i * BM;
+  const int n0 = nt_i * BN;
+
+  const float* in0 = p.in0 + (int64_t)zb * p.in0_bs + (int64_t)zh * p.in0_hs;
+  const float* in1 = p.in1 ? p.in1 + (int64_t)zb * p.in1_bs : nullptr;
+  const int T_in = p.T_in;
+  int len_in = T_in;
+  if (p.len_in) len_in = min(p.len_in[zb], T_in);
+
+  const int cpt = p.C_in / BK;   // 32-channel steps per tap
+  const int cp0 = p.C_in0 / BK;  // ... of which from in0 (== cpt without a concat input)
+  const int n_steps = p.n_taps * cpt;
+
+  // ---- operand cursors (run ahead of the MFMA phase; only load() touches them)
+  const int c4 = tid & 7;     // 16-B piece of the 128-B line
+  const int lrow = tid >> 3;  // tile rows lrow + 32 i
+  int a_tb[C::A_LD];          // input row of the tile row before the tap offset
+#pragma unroll
+  for (int i = 0; i < C::A_LD; ++i) a_tb[i] = min(t0 + lrow + 32 * i, p.T_out - 1) * p.in_stride;
+  const float* aptr[C::A_LD];
+  int abump[C::A_LD];  // floats per step: 32, or 0 on the zero page
+  int cur_tap = 0, cur_seg = 0, left = 0;
+  auto a_setup = [&](const int tap, const int seg) {
+    const float* src = seg == 0 ? in0 : in1;
+    const int ld = seg == 0 ? p.ld_in0 : p.ld_in1;
+    const int toff = p.tap_off[tap];
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i) {
+      int ti = a_tb[i] + toff;
+      if (p.pad_reflect) {
+        if (ti < 0) ti = -ti;
+        if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
+      }
+      const bool ok = ti >= 0 && ti < len_in;
+      aptr[i] = ok ? src + (int64_t)ti * ld + c4 * 4 : g_zero_page + c4 * 4;
+      abump[i] = ok ? BK : 0;
+    }
+    left = seg == 0 ? cp0 : cpt - cp0;
+  };
+  a_setup(0, 0);
+
+  const float* bptr[C::B_LD];  // WPL: 16-B piece c4 of the row's current 128-B plane line; else fp32 row + 4 c4
+#pragma unroll
+  for (int i = 0; i < C::B_LD; ++i) {
+    const int n = min(n0 + lrow + 32 * i, p.N - 1);  // columns >= N are computed on a clamped row, never stored
+    if constexpr (WPL)
+      bptr[i] = reinterpret_cast<const float*>(p.w_hi) + ((int64_t)n * n_steps * 32 + c4 * 4);
+    else
+      bptr[i] = p.w + (int64_t)zb * p.w_bs + (int64_t)zh * p.w_hs + (int64_t)n * p.ldw + c4 * 4;
+  }
+
+  struct Regs {
+    float4 pa[C::A_LD];
+    float4 pb[C::B_LD];
+  };
+  // issue-only: nothing here consumes a loaded value
+  auto load = [&](Regs& R) {
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i) {
+      R.pa[i] = *reinterpret_cast<const float4*>(aptr[i]);
+      aptr[i] += abump[i];
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_LD; ++i) {
+      R.pb[i] = *reinterpret_cast<const float4*>(bptr[i]);
+      bptr[i] += BK;
+    }
+    if (--left == 0) {  // wave-uniform, once per (tap, input tensor)
+      if (cur_seg == 0 && cp0 < cpt) {
+        cur_seg = 1;
+      } else {
+        cur_seg = 0;
+        ++cur_tap;
+      }
+      if (cur_tap < p.n_taps) a_setup(cur_tap, cur_seg);
+    }
+  };
+
+  const int pro_act = p.pro_act;
+  const float pro_slope = p.pro_slope;
+  const int st_off = bf_off(lrow, c4 * 4);          // A (and fp32 B) rows: 8-B slot of this thread's float4
+  const int stb_off = bf_off(lrow, (c4 & 3) * 8);   // plane B rows: 16-B slot of this thread's piece
+  auto store = [&](const int stage, Regs& R) {
+    unsigned char* sa_hi = smem_f + stage * C::STAGE;
+    unsigned char* sa_lo = sa_hi + BM * 64;
+    unsigned char* sb_hi = sa_lo + BM * 64;
+    unsigned char* sb_lo = sb_hi + BN * 64;
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i) {
+      float4 v = R.pa[i];
+      if constexpr (ACT == SRN_ACT_LEAKY) {
+        v.x = v.x > 0.f ? v.x : v.x * pro_slope;
+        v.y = v.y > 0.f ? v.y : v.y * pro_slope;
+        v.z = v.z > 0.f ? v.z : v.z * pro_slope;
+        v.w = v.w > 0.f ? v.w : v.w * pro_slope;
+      } else if constexpr (ACT < 0) {
+        v.x = srn_act(v.x, pro_act, pro_slope);
+        v.y = srn_act(v.y, pro_act, pro_slope);
+        v.z = srn_act(v.z, pro_act, pro_slope);
+        v.w = srn_act(v.w, pro_act, pro_slope);
+      }
+      uint2 hi, lo;
+      split_pair(v.x, v.y, hi.x, lo.x);
+      split_pair(v.z, v.w, hi.y, lo.y);
+      *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
+      *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
+    }
+    if constexpr (WPL) {
+      unsigned char* dst = (c4 < 4 ? sb_hi : sb_lo) + stb_off;
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) *reinterpret_cast<float4*>(dst + i * 2048) = R.pb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) {
+        const float4 v = R.pb[i];
+        uint2 hi, lo;
+        split_pair(v.x, v.y, hi.x, lo.x);
+        split_pair(v.z, v.w, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(sb_hi + st_off + i * 2048) = hi;
+        *reinterpret_cast<uint2*>(sb_lo + st_off + i * 2048) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  const int wm0 = (wave / C::WAVES_N) * C::WM;
+  const int wn0 = (wave % C::WAVES_N) * C::WN;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int sw = (li >> 2) & 3;  // row swizzle key (tile row offsets are multiples of 32)
+  const int fr_a = (wm0 + li) * 64;
+  const int fr_b = (wn0 + li) * 64;
+
+  auto compute = [&](const int stage) {
+    const unsigned char* sa_hi = smem_f + stage * C::STAGE;
+    const unsigned char* sa_lo = sa_hi + BM * 64;
+    const unsigned char* sb_hi = sa_lo + BM * 64;
+    const unsigned char* sb_lo = sb_hi + BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int choff = (((kk * 2 + lh) ^ sw) & 3) << 4;
+      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = *reinterpret_cast<const bf16x8*>(sa_hi + fr_a + m * 2048 + choff);
+        al[m] = *reinterpret_cast<const bf16x8*>(sa_lo + fr_a + m * 2048 + choff);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + fr_b + n * 2048 + choff);
+        bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + fr_b + n * 2048 + choff);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+    }
+  };
+
+  // MFMA phase of tile s and staging of tile s+1 in ONE basic block, interleaved by the scheduler: each MFMA holds
+  // the vector issue port for 8 of its 32 cycles, so ~5 VALU / LDS instructions ride along per MFMA.
+  auto fused = [&](const int cs, const int ss, Regs& R) {
+    compute(cs);
+    store(ss, R);
+    constexpr int N_MFMA = MT * NT * 6;
+    constexpr int N_DSR = (MT + NT) * 4;
+    constexpr int N_VALU = C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10);
+    constexpr int N_DSW = C::A_LD * 2 + (WPL ? C::B_LD : C::B_LD * 2);
+    constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
+    __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * 2, 0);  // fragments of the first k16 half
+#pragma unroll
+    for (int i = 0; i < N_MFMA; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < N_DSR - (MT + NT) * 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+      if (i * N_DSW / N_MFMA != (i + 1) * N_DSW / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+  };
+
+  // Pipeline: LDS double-buffered, two register sets; the loads of tile s+2 are issued before the MFMA phase of
+  // tile s, whose basic block also splits / writes tile s+1.
+  Regs R0, R1;
+  load(R0);
+  store(0, R0);
+  if (n_steps > 1) load(R0);
+  __syncthreads();
+  int step = 0;
+  // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (if it exists)
+  for (; step + 2 < n_steps; step += 2) {
+    load(R1);
+    fused(0, 1, R0);
+    __syncthreads();
+    if (step + 3 < n_steps) load(R0);
+    fused(1, 0, R1);
+    __syncthreads();
+  }
+  compute(0);
+  if (step + 1 < n_steps) {
+    store(1, R0);
+    __syncthreads();
+    compute(1);
+  }
+
+  conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+}
+
+template <class C, int ACT, bool WPL>
+int launch_fast3(const SrnConvParams& p, hipStream_t stream) {
+  constexpr int SMEM = C::SMEM_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fast_kernel<C, ACT, WPL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
+  const int n_tiles = (p.N + C::BN - 1) / C::BN;
+  const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
+  SRN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_fast: bad grid %lld", (long long)blocks);
+  hipLaunchKernelGGL((conv_fast_kernel<C, ACT, WPL>), dim3((unsigned)blocks), dim3(256), SMEM, stream, p, m_tiles,
+                     n_tiles);
+  SRN_CHECK_LAUNCH();
+  return 1;
+}
+
+template <class C, int ACT>
+int launch_fast2(const SrnConvParams& p, bool wpl, hipStream_t stream) {
+  return wpl ? launch_fast3<C, ACT, true>(p, stream) : launch_fast3<C, ACT, false>(p, stream);
+}
+
+template <class C>
+int launch_fast(const SrnConvParams& p, bool wpl, hipStream_t stream) {
+  if (p.pro_act == SRN_ACT_NONE) return launch_fast2<C, SRN_ACT_NONE>(p, wpl, stream);
+  if (p.pro_act == SRN_ACT_LEAKY) return launch_fast2<C, SRN_ACT_LEAKY>(p, wpl, stream);
+  return launch_fast2<C, -1>(p, wpl, stream);
+}
+
+}  // namespace
+
+// Returns 1 if the launch was handled, 0 if the shape is not eligible (caller falls back to the generic kernel),
+// < 0 on error.  `p` has been validated and defaulted by srn_conv_gemm.
+int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
+  if (p.precision != SRN_PREC_BF16X3 || p.w_nmajor) return 0;
+  if (p.C_in % BK != 0 || p.C_in0 % BK != 0) return 0;
+  const bool wpl = p.w_hi != nullptr && p.w_bs == 0 && p.w_hs == 0;
+  if (!wpl) {
+    // fp32 B rows walked contiguously over (tap, channel): needs the packed [tap][C_in] row layout, all of it live
+    if (p.C_w != p.C_in || p.ldw < p.n_taps * p.C_in) return 0;
+  }
+  switch (tile) {
+    case 1: return launch_fast<FCfg<128, 128, 64, 64>>(p, wpl, stream);
+    case 2: return launch_fast<FCfg<128, 64, 32, 64>>(p, wpl, stream);
+    case 3: return launch_fast<FCfg<64, 128, 32, 64>>(p, wpl, stream);
+    case 4: return launch_fast<FCfg<64, 64, 32, 32>>(p, wpl, stream);
+    case 5: return launch_fast<FCfg<128, 32, 32, 32>>(p, wpl, stream);
+    default: return 0;
+  }
+}

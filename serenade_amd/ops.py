@@ -78,12 +78,18 @@ class ConvOp:
         p.out, p.out_bs, p.out_hs, p.ld_out = _ptr(out), int(out_bs), int(out_hs), int(ld_out)
         p.gn_partials = _ptr(gn_partials)
         p.precision = int(DEFAULT_PRECISION if precision is None else precision)
-        p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 never, 2 force (when eligible)
+        p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 no halo kernel, 2 force halo, 3 generic kernel only
         self.p = p
         self._fn = _lib.lib().srn_conv_gemm
         self._ws = self._wplanes = None
-        if p.precision == _lib.PREC_BF16X3 and USE_PLANES and not geglu:
-            self._prepare_planes(w, int(n_batch) * int(n_head), bool(w_nmajor))
+        if p.precision == _lib.PREC_BF16X3:
+            # static weights are split once, at plan-build time, into the bf16 hi|lo plane image conv_fast.hip
+            # (and conv_planes.hip) stream straight into LDS
+            if isinstance(w, torch.Tensor) and w.is_cuda and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor:
+                self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw)
+                p.w_hi = self._wplanes[0].data_ptr()
+            if USE_PLANES and not geglu:
+                self._prepare_planes(w, int(n_batch) * int(n_head), bool(w_nmajor))
 
     # ---- split-bf16 fast path: operands as (hi, lo) bf16 planes in an HBM workspace (conv_planes.hip)
     def _prepare_planes(self, w, Z, w_nmajor):
@@ -91,10 +97,7 @@ class ConvOp:
         cp = (p.C_in + 31) // 32 * 32
         static_w = isinstance(w, torch.Tensor) and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor and w.is_cuda
         w_total = 0
-        if static_w:
-            self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw)
-            p.w_hi = self._wplanes[0].data_ptr()
-        else:
+        if not static_w:
             if p.n_taps != 1:
                 return  # multi-tap with non-static weights: not supported by the planes path
             w_total = p.N * p.n_taps * cp * (Z if (p.w_bs or p.w_hs) else 1)

@@ -83,8 +83,11 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     """run the kernel (for each tile id) and the spec on clones of the same inputs; compare every buffer"""
     base = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
     tol = KTOL.k if tol is None else tol
-    planes = (False, True) if serenade_amd.get_precision() == "bf16x3" else (False,)
-    for tile, use_ws in [(t, u) for t in tiles for u in planes]:
+    # split-bf16 has three kernels behind the one entry point: conv_fast (regular shapes; auto), the LDS-DMA planes
+    # pipeline (workspace attached) and the generic conv_gemm kernel (no_halo=3 forces it)
+    variants = ("auto", "planes", "generic") if serenade_amd.get_precision() == "bf16x3" else ("auto",)
+    for tile, variant in [(t, u) for t in tiles for u in variants]:
+        use_ws = variant == "planes"
         cpu = {}
         memo = {}
 
@@ -102,6 +105,10 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
         m = Mirror(dev)
         gpu = {k: m(v) for k, v in cpu.items()}
         gpu["tile"] = tile
+        if variant == "generic":
+            if gpu.get("no_halo"):
+                continue
+            gpu["no_halo"] = 3
         saved, ops.USE_PLANES = ops.USE_PLANES, use_ws
         try:
             op = ops.ConvOp(**gpu)
@@ -117,7 +124,7 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
         for c, g in m.pairs():
             if c.is_floating_point():
                 e = nerr(g, c)
-                assert e < tol, f"tile {tile} planes {use_ws}: mismatch {e}"
+                assert e < tol, f"tile {tile} {variant}: mismatch {e}"
     del base
 
 
