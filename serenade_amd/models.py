@@ -255,8 +255,11 @@ class DecoderPlan:
         bufC, bufA, bufR = f(B, L, Cmax), f(B, L, Cmax), f(B, L, Cmax)
         bufN = f(B, L, Cmax)
         qkv = f(B, L, 3 * inner)
-        Lp = _rup(L, 4)
+        Lp = _rup(L, 32)
         S = f(B * H, L, Lp)
+        # V^T per resolution, (B, inner, rup(T, 32)): P.V then contracts k-major rows like every other GEMM.  The pad
+        # columns are never written (zeros from allocation) and meet exact zeros of the softmax.
+        Vt = {T: f(B, inner, _rup(T, 32)) for T in sorted(set(Ts))}
         bufO = f(B, L, inner)
         ffh = max(t["ff2_w"].shape[1] for t in P["tfm"])
         bufG = f(B, L, ffh)
@@ -264,7 +267,7 @@ class DecoderPlan:
         gnp = f(B, (L + 31) // 32, Cmax // 32, 2)
         self.dphi = f(B, L, oc) if not euler else None
         self.out_ct = f(B, oc, L)
-        self._keep = (bufX, bufY, bufC, bufA, bufR, bufN, qkv, S, bufO, bufG, hid, gnp)
+        self._keep = (bufX, bufY, bufC, bufA, bufR, bufN, qkv, S, Vt, bufO, bufG, hid, gnp)
 
         # ---- once-per-solve conditioning ops (time embedding for all steps, speaker affine)
         tdim = dec.in_channels
@@ -317,9 +320,10 @@ class DecoderPlan:
         def tfm(ol, bi, lvl, X, C):
             t = P["tfm"][bi]
             T, ln = Ts[lvl], self.lens[lvl]
-            Tp = _rup(T, 4)
+            Tp = _rup(T, 32)
             ol.append(ops.layernorm_op(X, t["ln1_w"], t["ln1_b"], bufN, B * T, C))
             ol.append(conv(bufN, C, T, t["qkv_w"], None, qkv, 3 * inner, T, [0]))
+            ol.append(ops.transpose_op((qkv, 2 * inner), Vt[T], B, T, inner, T * 3 * inner, 3 * inner, inner * Tp, Tp))
             # S = Q K^T / sqrt(d)   (batched over B x heads)
             ol.append(ConvOp(in0=qkv, w=(qkv, inner), out=S, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=hd, N=T,
                              in0_bs=T * 3 * inner, in0_hs=hd, ld_in0=3 * inner, w_bs=T * 3 * inner, w_hs=hd,
@@ -327,9 +331,9 @@ class DecoderPlan:
                              alpha=1.0 / math.sqrt(hd)))
             ol.append(ops.softmax_rows_op(S, ln, B * H, H, T, Tp))
             # O = P V
-            ol.append(ConvOp(in0=S, w=(qkv, 2 * inner), out=bufO, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=Tp,
-                             C_w=T, N=hd, in0_bs=H * T * Tp, in0_hs=T * Tp, ld_in0=Tp, w_bs=T * 3 * inner, w_hs=hd,
-                             ldw=3 * inner, w_nmajor=True, out_bs=T * inner, out_hs=hd, ld_out=inner))
+            ol.append(ConvOp(in0=S, w=Vt[T], out=bufO, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=Tp, N=hd,
+                             in0_bs=H * T * Tp, in0_hs=T * Tp, ld_in0=Tp, w_bs=inner * Tp, w_hs=hd * Tp, ldw=Tp,
+                             out_bs=T * inner, out_hs=hd, ld_out=inner))
             ol.append(conv(bufO, inner, T, t["o_w"], t["o_b"], X, C, T, [0], res=X, res_mode=RES_ADD, res_bs=T * C,
                            ld_res=C))
             ol.append(ops.layernorm_op(X, t["ln3_w"], t["ln3_b"], bufN, B * T, C))
