@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
       bptr[i] = p.w + (int64_t)zb * p.w_bs + (int64_t)zh * p.w_hs + (int64_t)n * p.ldw + c4 * 4;
   }
 
+  int bbump = BK;  // floats per step (0 once the cursor is parked)
   struct Regs {
     float4 pa[C::A_LD];
     float4 pb[C::B_LD];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
 #pragma unroll
     for (int i = 0; i < C::B_LD; ++i) {
       R.pb[i] = *reinterpret_cast<const float4*>(bptr[i]);
-      bptr[i] += BK;
+      bptr[i] += bbump;
     }
     if (--left == 0) {  // wave-uniform, once per (tap, input tensor)
       if (cur_seg == 0 && cp0 < cpt) {
@@ -137,7 +138,22 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
         cur_seg = 0;
         ++cur_tap;
       }
-      if (cur_tap < p.n_taps) a_setup(cur_tap, cur_seg);
+      if (cur_tap < p.n_taps) {
+        a_setup(cur_tap, cur_seg);
+      } else {
+        // past the last step: the pipeline issues up to two more (unconditional) loads; park the cursors on
+        // valid memory.  Unconditional loads keep hipcc's s_waitcnt vmcnt(N) counted -- with a load under an
+        // `if` it must assume the newer loads may not exist and waits vmcnt(0), i.e. for the loads just issued.
+#pragma unroll
+        for (int i = 0; i < C::A_LD; ++i) {
+          aptr[i] = g_zero_page + c4 * 4;
+          abump[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_LD; ++i) bptr[i] -= BK;
+        bbump = 0;
+        left = 1 << 30;
+      }
     }
   };
 
@@ -265,15 +281,15 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
   Regs R0, R1;
   load(R0);
   store(0, R0);
-  if (n_steps > 1) load(R0);
+  load(R0);
   __syncthreads();
   int step = 0;
-  // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (if it exists)
+  // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (or a parked dummy)
   for (; step + 2 < n_steps; step += 2) {
     load(R1);
     fused(0, 1, R0);
     __syncthreads();
-    if (step + 3 < n_steps) load(R0);
+    load(R0);
     fused(1, 0, R1);
     __syncthreads();
   }
