@@ -22,6 +22,10 @@ constexpr int BK = 32;
 // 256 B of zeros: the source of every padded / masked operand row
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
 
+#ifdef SRN_DBG_TIMING
+__device__ unsigned long long g_dbg[1024 * 4 * 4];
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     float4 pb[C::B_LD];
   };
   // issue-only: nothing here consumes a loaded value
-  auto load = [&](Regs& R) {
+  auto load_issue = [&](Regs& R) {
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
       R.pa[i] = *reinterpret_cast<const float4*>(aptr[i]);
@@ -131,6 +135,8 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
       R.pb[i] = *reinterpret_cast<const float4*>(bptr[i]);
       bptr[i] += bbump;
     }
+  };
+  auto cursor_advance = [&]() {
     if (--left == 0) {  // wave-uniform, once per (tap, input tensor)
       if (cur_seg == 0 && cp0 < cpt) {
         cur_seg = 1;
@@ -258,12 +264,16 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
 
   // MFMA phase of tile s and staging of tile s+1 in ONE basic block, interleaved by the scheduler: each MFMA holds
   // the vector issue port for 8 of its 32 cycles, so ~5 VALU / LDS instructions ride along per MFMA.
-  auto fused = [&](const int cs, const int ss, Regs& R) {
+  // The global loads of tile s+2 ride in the same block (one per ~3 MFMAs): issued back to back ahead of the MFMAs
+  // they cost the wave ~565 cycles per step waiting on the address / data path with its MFMA queue empty.
+  auto fused = [&](const int cs, const int ss, Regs& Rs, Regs& Rl) {
     compute(cs);
-    store(ss, R);
+    store(ss, Rs);
+    load_issue(Rl);
     constexpr int N_MFMA = MT * NT * 6;
     constexpr int N_DSR = (MT + NT) * 4;
-    constexpr int N_VALU = C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10);
+    constexpr int N_LD = C::A_LD + C::B_LD;
+    constexpr int N_VALU = C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10) + N_LD;
     constexpr int N_DSW = C::A_LD * 2 + (WPL ? C::B_LD : C::B_LD * 2);
     constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
     __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * 2, 0);  // fragments of the first k16 half
@@ -271,12 +281,17 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     for (int i = 0; i < N_MFMA; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (i < N_DSR - (MT + NT) * 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i * N_LD / N_MFMA != (i + 1) * N_LD / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
       if (i * N_DSW / N_MFMA != (i + 1) * N_DSW / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
   };
+  auto load = [&](Regs& R) {
+    load_issue(R);
+    cursor_advance();
+  };
 
-  // Pipeline: LDS double-buffered, two register sets; the loads of tile s+2 are issued before the MFMA phase of
+  // Pipeline: LDS double-buffered, two register sets; the loads of tile s+2 are issued inside the MFMA phase of
   // tile s, whose basic block also splits / writes tile s+1.
   Regs R0, R1;
   load(R0);
@@ -285,14 +300,43 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
   __syncthreads();
   int step = 0;
   // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (or a parked dummy)
-  for (; step + 2 < n_steps; step += 2) {
-    load(R1);
-    fused(0, 1, R0);
-    __syncthreads();
-    load(R0);
-    fused(1, 0, R1);
-    __syncthreads();
+#ifdef SRN_DBG_TIMING
+  // developer build: per-wave cycle counts of the three loop segments (issue / MFMA+staging / barrier wait)
+  unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tk_start = __builtin_readcyclecounter();
+#define SRN_TICK(acc_)                                          \
+  {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc_ += now_ - tk_start;                                    \
+    tk_start = now_;                                            \
+    __builtin_amdgcn_sched_barrier(0);                          \
   }
+#else
+#define SRN_TICK(acc_)
+#endif
+  for (; step + 2 < n_steps; step += 2) {
+    fused(0, 1, R0, R1);
+    SRN_TICK(tq1)
+    cursor_advance();
+    SRN_TICK(tq0)
+    __syncthreads();
+    SRN_TICK(tq2)
+    fused(1, 0, R1, R0);
+    SRN_TICK(tq1)
+    cursor_advance();
+    SRN_TICK(tq0)
+    __syncthreads();
+    SRN_TICK(tq2)
+  }
+#ifdef SRN_DBG_TIMING
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* d = g_dbg + (blockIdx.x * 4 + wave) * 4;
+    d[0] = tq0;
+    d[1] = tq1;
+    d[2] = tq2;
+    d[3] = (unsigned long long)(step / 2);
+  }
+#endif
   compute(0);
   if (step + 1 < n_steps) {
     store(1, R0);
@@ -355,3 +399,10 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
     default: return 0;
   }
 }
+
+#ifdef SRN_DBG_TIMING
+// developer build only: copy the per-wave segment cycle counts of the last conv_fast launch to the host
+extern "C" int srn_dbg_timing(unsigned long long* host_dst, int n_words) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU): sample rocm-smi clocks / power while a long GEMM loop runs."""
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from serenade_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    M, N, K = 10240, 2048, 2048
+    x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    out = torch.empty(M, N, device=dev)
+    prec = _lib.PREC_FP32 if "--fp32" in sys.argv else _lib.PREC_BF16X3
+    op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
+                    precision=prec, tile=1)
+    stop = False
+
+    def watch():
+        while not stop:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True)
+            for ln in r.stdout.splitlines():
+                if "sclk" in ln or "Power" in ln or "mclk" in ln:
+                    print(ln.strip(), flush=True)
+            time.sleep(0.5)
+
+    th = threading.Thread(target=watch)
+    th.start()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 4.0:
+        for _ in range(200):
+            op()
+        torch.cuda.synchronize()
+        n += 200
+    el = time.time() - t0
+    stop = True
+    th.join()
+    print(f"{n} launches in {el:.2f} s -> {el / n * 1e6:.1f} us each, {2.0 * M * N * K * n / el / 1e12:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
