@@ -97,7 +97,9 @@ typedef struct SrnConvParams {
   const float* res2; int64_t res2_bs; int32_t ld_res2;  /* second additive residual (HiFi-GAN stage sum) */
   float* out; int64_t out_bs, out_hs; int32_t ld_out;
   int32_t precision;  /* SRN_PREC_* */
-  int32_t no_halo;    /* receptive-field (halo) kernel variant: 0 = automatic, 1 = never, 2 = whenever eligible (testing / A-B timing) */
+  int32_t no_halo;    /* kernel selection behind this entry point (testing / A-B timing): 0 = automatic, 1 = tiled kernels
+                       * only (no halo, no strip), 2 = halo kernel whenever eligible, 3 = generic conv_gemm kernel only,
+                       * 4 = strip kernel whenever eligible */
   /* split-bf16 fast path (conv_planes.hip): an HBM workspace into which the operands are split once into (hi, lo)
    * bf16 planes and from which the GEMM streams them with LDS-DMA.  ws == NULL selects the in-kernel split path.
    * w_hi: weights already split at load time, bf16 [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32] (NULL: split per

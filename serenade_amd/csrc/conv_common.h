@@ -190,3 +190,5 @@ int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);
 int srn_conv_planes_try(const SrnConvParams& p, int tile, hipStream_t stream);
 // implemented in conv_fast.hip: lean split-bf16 kernel for C_in % 32 == 0, k-major weights.  Same return codes.
 int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream);
+// implemented in conv_strip.hip: thin convs (C_in, N in {32, 64}) with the whole weight tensor LDS-resident.
+int srn_conv_strip_try(const SrnConvParams& p, hipStream_t stream);

@@ -244,6 +244,27 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
         bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + fr_b + n * 2048 + choff);
         bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + fr_b + n * 2048 + choff);
       }
+#ifdef SRN_DBG_MFMA16
+      // timing-only experiment (wrong arithmetic): the same FLOPs issued as 16x16x32 MFMAs
+      {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                f32x4 c;
+                const int o = (kk * 2 + h) * 4;
+                c[0] = acc[m][n][o], c[1] = acc[m][n][o + 1], c[2] = acc[m][n][o + 2], c[3] = acc[m][n][o + 3];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t == 0 ? al[m] : ah[m], t == 1 ? bl[n] : bh[n], c, 0, 0, 0);
+                acc[m][n][o] = c[0], acc[m][n][o + 1] = c[1], acc[m][n][o + 2] = c[2], acc[m][n][o + 3] = c[3];
+              }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -541,6 +541,11 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
     if (r != 0) return r < 0 ? r : 0;
   }
   if (p.no_halo != 1 && p.no_halo != 3) {
+    // thin convs (<= 64 channels in and out): persistent strip kernel with LDS-resident weights
+    const int r = srn_conv_strip_try(p, stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
+  if (p.no_halo != 1 && p.no_halo != 3) {
     // stride-1 multi-tap convs in split-bf16: stage the receptive-field tile once per channel chunk
     const int r = srn_conv_halo_try(p, tile, stream);
     if (r != 0) return r < 0 ? r : 0;

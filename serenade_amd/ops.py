@@ -78,7 +78,7 @@ class ConvOp:
         p.out, p.out_bs, p.out_hs, p.ld_out = _ptr(out), int(out_bs), int(out_hs), int(ld_out)
         p.gn_partials = _ptr(gn_partials)
         p.precision = int(DEFAULT_PRECISION if precision is None else precision)
-        p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 no halo kernel, 2 force halo, 3 generic kernel only
+        p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 tiled kernels only, 2 force halo, 3 generic kernel only, 4 force strip
         self.p = p
         self._fn = _lib.lib().srn_conv_gemm
         self._ws = self._wplanes = None
