@@ -124,6 +124,20 @@ __device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x1
       const unsigned q_v = (unsigned)(4 * lh * ts) * (unsigned)p.ld_res2 + li;
       const int64_t q_rs = (int64_t)ts * p.ld_res2;
       float s1 = 0.f, s2 = 0.f;
+      // Residuals of the whole sub-tile first, back to back: `res` / `res2` may alias `out`, so the compiler cannot
+      // move a residual load above an earlier store and a load-per-row loop pays one memory round trip per row
+      // (16 per sub-tile).  Reading before writing is safe for the supported aliasing: a lane reads exactly the
+      // elements it later writes.
+      float rv[16], qv[16];
+      if constexpr (RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = interior || (col_ok && tm + dr + 4 * lh < p.T_out);
+          rv[r] = (r_u && ok) ? (r_u + dr * r_rs)[r_v] : 0.f;
+          qv[r] = (q_u && ok) ? (q_u + dr * q_rs)[q_v] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);  // compile-time row of this register (+ 4 lh per lane)
@@ -137,9 +151,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x1
         const bool ok = interior || (col_ok && trow < p.T_out);
         if (ok) {
           if constexpr (RES) {
-            if (res_mode == SRN_RES_ADD) v += (r_u + dr * r_rs)[r_v];
-            else if (res_mode == SRN_RES_AXPY) v = (r_u + dr * r_rs)[r_v] + p.beta * v;
-            if (q_u) v += (q_u + dr * q_rs)[q_v];
+            if (res_mode == SRN_RES_ADD) v += rv[r];
+            else if (res_mode == SRN_RES_AXPY) v = rv[r] + p.beta * v;
+            if (q_u) v += qv[r];
             if (post == SRN_POST_DIV) v = v / p.post_div;
             else if (post == SRN_POST_TANH) v = tanhf(v);
             else if (post == SRN_POST_RELU) v = fmaxf(v, 0.f);

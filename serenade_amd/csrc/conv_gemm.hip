@@ -485,7 +485,10 @@ int pick_tile(const SrnConvParams& p) {
     double quant = blocks / (256.0 * (double)(int64_t)rounds);
     // fewer blocks than CUs idles CUs outright; beyond one round, co-resident blocks absorb part of the tail
     if (blocks > 256.0) quant = 0.35 + 0.65 * quant;
-    const float score = (float)(useful * quant) * t.base[p.precision == SRN_PREC_BF16X3 ? 1 : 0];
+    float score = (float)(useful * quant) * t.base[p.precision == SRN_PREC_BF16X3 ? 1 : 0];
+    // both operands split in the loop (Q K^T, P V): the 64x128 tile measured 5-10 % ahead of 128x128
+    if (p.precision == SRN_PREC_BF16X3 && (p.w_hi == nullptr || p.w_bs != 0 || p.w_hs != 0) && t.id == 1)
+      score *= 0.92f;
     if (score > best) {
       best = score;
       best_id = t.id;
