@@ -213,9 +213,10 @@ int srn_conv_strip_try(const SrnConvParams& p, hipStream_t stream) {
   if (hi - lo > HALO_MAX) return 0;
   const int smem = p.n_taps * p.C_in * p.N * 4 + (p.C_in / 32) * 2 * HR_MAX * 64;
   if (smem > 160 * 1024) return 0;
-  // measured on the HiFi-GAN 32-channel stage: faster than the tiled kernels only with >= 3 workgroups per CU
-  // (k3 0.242 -> 0.213 ms, k7 0.328 -> 0.301 ms); with 2 (k11: 68 KB) or 1 the exposed load latency loses
-  if (!force && smem > 52 * 1024) return 0;
+  // measured on the HiFi-GAN stages (8 x 245760 x 32 and 8 x 122880 x 64): ahead of the tiled kernels with >= 2
+  // workgroups per CU (32 channels: k3 0.242 -> 0.212, k7 0.328 -> 0.190, k11 0.355 -> 0.274 ms); with one (64
+  // channels: 95-160 KB) the exposed load latency loses (k3 0.201 -> 0.445 ms)
+  if (!force && smem > 78 * 1024) return 0;
   if (p.C_in == 32 && p.N == 32) return launch_strip_act<32, 1>(p, lo, hi - lo, stream);
   if (p.C_in == 32 && p.N == 64) return launch_strip_act<32, 2>(p, lo, hi - lo, stream);
   if (p.C_in == 64 && p.N == 32) return launch_strip_act<64, 1>(p, lo, hi - lo, stream);
