@@ -53,6 +53,15 @@ struct FCfg {
 
 // ACT: SRN_ACT_NONE / SRN_ACT_LEAKY compile-time, -1 = run-time p.pro_act (SiLU / Mish).
 // WPL: B operand is the pre-split weight plane image (p.w_hi); otherwise fp32 rows split in the loop (Q K^T).
+// APL (developer builds, -DSRN_DBG_APL): the A operand arrives as bf16 hi|lo planes too, so the loop has no split at
+// all.  Measured on 10240 x 2048 x 2048: 350 vs 341 TFLOP/s (+2.7 %) -- the in-loop split is not what bounds the
+// kernel, so activation producers keep writing plain fp32.
+#ifdef SRN_DBG_APL
+constexpr bool APL = true;
+#else
+constexpr bool APL = false;
+#endif
+
 template <class C, int ACT, bool WPL>
 __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
                                                            const int n_tiles) {
@@ -172,6 +181,17 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     unsigned char* sa_lo = sa_hi + BM * 64;
     unsigned char* sb_hi = sa_lo + BM * 64;
     unsigned char* sb_lo = sb_hi + BN * 64;
+    if constexpr (APL) {
+      unsigned char* dsta = (c4 < 4 ? sa_hi : sa_lo) + stb_off;
+#pragma unroll
+      for (int i = 0; i < C::A_LD; ++i) {
+        // pass the value through an opaque asm: a pure global -> register -> LDS copy of the whole set is turned
+        // into memcpys of a stack object (scratch) by the optimizer
+        float4 v = R.pa[i];
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        *reinterpret_cast<float4*>(dsta + i * 2048) = v;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
       float4 v = R.pa[i];
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
       split_pair(v.z, v.w, hi.y, lo.y);
       *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
       *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
+    }
     }
     if constexpr (WPL) {
       unsigned char* dst = (c4 < 4 ? sb_hi : sb_lo) + stb_off;
@@ -294,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     constexpr int N_MFMA = MT * NT * 6;
     constexpr int N_DSR = (MT + NT) * 4;
     constexpr int N_LD = C::A_LD + C::B_LD;
-    constexpr int N_VALU = C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10) + N_LD;
-    constexpr int N_DSW = C::A_LD * 2 + (WPL ? C::B_LD : C::B_LD * 2);
+    constexpr int N_VALU = (APL ? 0 : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18)) + (WPL ? 0 : C::B_LD * 10) + N_LD;
+    constexpr int N_DSW = (APL ? C::A_LD : C::A_LD * 2) + (WPL ? C::B_LD : C::B_LD * 2);
     constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
     __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * 2, 0);  // fragments of the first k16 half
 #pragma unroll
