@@ -74,13 +74,21 @@ def cpu_baseline(sd, gsd):
 
 
 def main():
+    global B_PER_GPU, T_SRC, T_REF, N_EULER
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-fp32", action="store_true", help="profiling runs: time the headline split-bf16 mode only")
+    ap.add_argument("--graphs", type=int, default=None, help="1/0: replay the plans as hipGraphs (default: library default)")
+    # the north-star's other sizes (T in {256, 1024, 4096}, 20 Euler steps); the defaults are the headline workload
+    ap.add_argument("--frames", type=int, default=T_SRC, help="source mel frames per utterance")
+    ap.add_argument("--ref-frames", type=int, default=T_REF, help="prompt frames per utterance")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU")
+    ap.add_argument("--euler", type=int, default=N_EULER, help="Euler ODE steps")
     args = ap.parse_args()
+    B_PER_GPU, T_SRC, T_REF, N_EULER = args.batch, args.frames, args.ref_frames, args.euler
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +112,7 @@ def main():
     def step():
         mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"],
                               g["ref_logmel"], g["ref_midi"], g["ref_lft"], n_timesteps=N_EULER, noise=g["z"])
-        wave = voc.decode_batch(mel)
+        wave = voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))  # inference() squeezes B == 1
         return gather_waveforms(wave, dst=0) if world > 1 else wave
 
     def sync():
@@ -113,6 +121,8 @@ def main():
         torch.cuda.synchronize()
 
     import serenade_amd
+    if args.graphs is not None:
+        ops.set_graphs(bool(args.graphs))
 
     fl = algorithmic_flops(B_PER_GPU, T_SRC, T_REF, N_EULER)
 
@@ -158,7 +168,7 @@ def main():
     value, elapsed, roof = timed("bf16x3")
     v32, e32, roof32 = (0.0, 0.0, None) if args.skip_fp32 else timed("fp32")
     out = {
-        "metric": "mel frames/sec converted (UNet ODE + vocoder), 80x1024",
+        "metric": f"mel frames/sec converted (UNet ODE + vocoder), 80x{T_SRC}",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate",

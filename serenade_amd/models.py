@@ -409,6 +409,7 @@ class DecoderPlan:
         self._build_step = build_step
         self.steps = None
         self._dts = None
+        self._runner = ops.GraphRunner(lambda: self.pre + [op for ol in self.steps for op in ol])
         self.io_in = [
             None,  # x transpose (set_inputs fills src)
         ]
@@ -430,6 +431,7 @@ class DecoderPlan:
             self.steps = [self._build_step(k, dts[k]) for k in range(self.n)]
             self._dts = dts
             ops.attach_workspace(self.pre + [op for ol in self.steps for op in ol], self.h0.device)
+            self._runner.invalidate()
 
     def set_lens(self, lens):
         lens = torch.as_tensor(lens).to(torch.int64).cpu()
@@ -449,11 +451,7 @@ class DecoderPlan:
             op()
 
     def run(self):
-        for op in self.pre:
-            op()
-        for ol in self.steps:
-            for op in ol:
-                op()
+        self._runner()
 
     def read_out(self):
         self.store_op()

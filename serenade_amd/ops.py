@@ -280,3 +280,47 @@ def pack_geglu(w, b):
     idx = torch.arange(inner, device=w.device).view(-1, 32)
     order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
     return w[order].contiguous(), b[order].contiguous()
+
+
+# ------------------------------------------------------------------ hipGraph replay of a fixed op list
+GRAPHS = os.environ.get("SERENADE_AMD_GRAPHS", "0") == "1"
+
+
+def set_graphs(enabled):
+    """Replay plans (the per-utterance-batch op lists) as captured hipGraphs.  Pays off when launches, not kernels,
+    bound the step: B=1 / short utterances (~1600 launches of 5-20 us each)."""
+    global GRAPHS
+    GRAPHS = bool(enabled)
+
+
+class GraphRunner:
+    """Runs `get_ops()` (a flat list of ConvOp / CallOp over static buffers) eagerly, or -- with GRAPHS on -- as one
+    captured hipGraph.  The first call is always eager (every kernel sets its attributes and loads its code object
+    outside capture); per-launch profiling (PROFILE) always runs eagerly.  `invalidate()` after any change of the op
+    list or of a buffer address baked into it."""
+
+    def __init__(self, get_ops):
+        self._get_ops = get_ops
+        self._graph = None
+        self._warm = False
+
+    def invalidate(self):
+        self._graph = None
+        self._warm = False
+
+    def __call__(self):
+        op_list = self._get_ops()
+        if not GRAPHS or PROFILE is not None or not self._warm or not torch.cuda.is_available():
+            for op in op_list:
+                op()
+            self._warm = True
+            return
+        if self._graph is None:
+            g = torch.cuda.CUDAGraph()
+            # callers run under torch.inference_mode() (flow_matching.py:39); capture bookkeeping (generator state
+            # registration) must happen outside it.  Only C-ABI launches are recorded, no torch ops.
+            with torch.inference_mode(False), torch.cuda.graph(g):
+                for op in op_list:
+                    op()
+            self._graph = g
+        self._graph.replay()

@@ -230,12 +230,12 @@ class HiFiGANPlan:
             # the next stage's upsample reads `acc` and writes `u`; resblocks then overwrite acc only at their end
         ol.append(ops.out_conv_tanh_op(cur, P["out_w"], P["out_b"], self.wave, B, tcur, ccur, gen.kernel_size, 0.01))
         self.ops = ol
+        self._runner = ops.GraphRunner(lambda: self.ops)
         self._keep = (h, u, p0, p1, xt, acc)
         ops.attach_workspace(ol, dev)
 
     def run(self):
-        for op in self.ops:
-            op()
+        self._runner()
 
 
 def load_vocoder(checkpoint, config=None, stats=None):

@@ -538,3 +538,22 @@ def test_training_forward_values_golden(dev, model, golden):
     assert nerr(ret["gauss_mel"], g["gauss_mel"]) < 5 * KTOL.k
     assert abs(ret["prior_loss"].item() / float(g["prior_loss"]) - 1) < 1e-4
     assert abs(ret["cfm_loss"].item() / float(g["cfm_loss"]) - 1) < 1e-3
+
+
+def test_hipgraph_replay_is_bitwise_the_eager_run(dev, model, voc):
+    """ops.set_graphs(True): the plans (Euler loop, HiFi-GAN) replay as captured hipGraphs -- same launches, same bits"""
+    d = synth_inputs(2, 72, T_ref=24, seed=77, lengths=[72, 50])
+    outs = []
+    try:
+        for graphs in (False, True):
+            ops.set_graphs(graphs)
+            for m in model.modules():  # fresh plans, so the graph arm captures its own
+                if hasattr(m, "_plans"):
+                    m._plans = {}
+            for _ in range(3):  # eager warm-up call, capturing call, replay
+                mel = _infer(model, d, dev, noise=d["z"])
+                wave = voc[0].decode_batch(mel)
+            outs.append((mel.cpu(), wave.cpu()))
+    finally:
+        ops.set_graphs(False)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
