@@ -1,17 +1,29 @@
 #!/bin/bash
-# developer tool: build timing-only variants of the library (operands from one tile; parts of the loop removed)
+# Developer tool: build a timing-only / instrumented variant of the library next to the product build.
+#
+#   tools/dbg_variants.sh NAME SOURCE.hip -DFLAG [-DFLAG ...]
+#
+# compiles serenade_amd/csrc/SOURCE.hip with the flags and links it with the product objects of every other source
+# into build_dbg/lib_NAME.so; run a tool against it with  SERENADE_AMD_LIB=$PWD/build_dbg/lib_NAME.so python tools/...
+#
+# Variants used for DESIGN.md section 6:
+#   tools/dbg_variants.sh SAME    conv_gemm.hip -DSRN_DEBUG_SAMETILE                  (every block reads tile (0,0))
+#   tools/dbg_variants.sh NOMFMA  conv_gemm.hip -DSRN_DEBUG_SAMETILE -DSRN_DBG_NOMFMA
+#   tools/dbg_variants.sh NOSTORE conv_gemm.hip -DSRN_DEBUG_SAMETILE -DSRN_DBG_NOSTORE
+#   tools/dbg_variants.sh NOLOAD  conv_gemm.hip -DSRN_DEBUG_SAMETILE -DSRN_DBG_NOLOAD
+#   tools/dbg_variants.sh TIMING  conv_fast.hip -DSRN_DBG_TIMING                      (tools/looptime.py)
+#   tools/dbg_variants.sh M16     conv_fast.hip -DSRN_DBG_MFMA16                      (16x16x32 MFMA issue, wrong math)
+#   tools/dbg_variants.sh APL     conv_fast.hip -DSRN_DBG_APL                         (A operand as planes)
 set -e
 cd "$(dirname "$0")/.."
+name=$1; src=$2; shift 2
+python -c "from serenade_amd import build; build.build(verbose=False)"
 mkdir -p build_dbg
-for v in BASE NOMFMA NOSTORE NOLOAD "NOLOAD -DSRN_DBG_NOSTORE"; do
-  name=$(echo "$v" | tr -d ' -' | sed 's/DSRN_DBG_//')
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Iinclude -Iserenade_amd/csrc \
-    -DSRN_DEBUG_SAMETILE -DSRN_DBG_$v -c serenade_amd/csrc/conv_gemm.hip -o build_dbg/conv_gemm_$name.o &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Iinclude -Iserenade_amd/csrc "$@" \
+  -c serenade_amd/csrc/$src -o build_dbg/${src}_$name.o
+objs=""
+for o in serenade_amd/build/*.o; do
+  case "$o" in *"/$src.o") ;; *) objs="$objs $o";; esac
 done
-wait
-for v in BASE NOMFMA NOSTORE NOLOAD NOLOADNOSTORE; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_dbg/lib_$v.so build_dbg/conv_gemm_$v.o \
-    serenade_amd/build/conv_halo.hip.o serenade_amd/build/conv_planes.hip.o serenade_amd/build/norm_act.hip.o \
-    serenade_amd/build/gst.hip.o serenade_amd/build/api.cpp.o
-done
-ls -la build_dbg/*.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_dbg/lib_$name.so build_dbg/${src}_$name.o $objs
+ls -la build_dbg/lib_$name.so
