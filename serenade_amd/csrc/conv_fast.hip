@@ -40,15 +40,19 @@ __device__ __forceinline__ void split_pair(const float a, const float b, unsigne
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
 }
 
-template <int BM_, int BN_, int WM_, int WN_>
+// NSTAGE: LDS stages.  2: tile s+1 is split / written while tile s is multiplied.  1: the two phases alternate
+// between barriers inside a workgroup and a third co-resident workgroup (32 KB each) supplies the overlap.
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_ = 2>
 struct FCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
   static constexpr int MT = WM / 32, NT = WN / 32;
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
   static constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per step
   static constexpr int STAGE = (BM + BN) * 128;          // [A_hi | A_lo | B_hi | B_lo], 64 B per tile row
-  static constexpr int SMEM_BYTES = 2 * STAGE;
+  static constexpr int SMEM_BYTES = NSTAGE * STAGE;
+  // workgroups per CU the kernel is compiled for (register budget 512 / waves per SIMD): three where the LDS allows
+  static constexpr int MIN_BLOCKS = SMEM_BYTES * 3 <= 160 * 1024 ? 3 : 2;
 };
 
 // ACT: SRN_ACT_NONE / SRN_ACT_LEAKY compile-time, -1 = run-time p.pro_act (SiLU / Mish).
@@ -63,7 +67,7 @@ constexpr bool APL = false;
 #endif
 
 template <class C, int ACT, bool WPL>
-__global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
+__global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
                                                            const int n_tiles) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
@@ -253,7 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     const unsigned char* sb_lo = sb_hi + BN * 64;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
+#ifdef SRN_DBG_HALFLDS  // timing-only experiment (wrong arithmetic): the second k16 half re-reads nothing from LDS
+      const int choff = (((lh) ^ sw) & 3) << 4;
+#else
       const int choff = (((kk * 2 + lh) ^ sw) & 3) << 4;
+#endif
       bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -332,6 +340,23 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const SrnConvParams p
     load_issue(R);
     cursor_advance();
   };
+
+  if constexpr (C::NSTAGE == 1) {
+    // One LDS stage, one register set: [split / write tile s | barrier | loads of tile s+1 issued, MFMAs of tile s |
+    // barrier].  Nothing overlaps inside the workgroup; three co-resident workgroups overlap each other.
+    Regs R;
+    load(R);
+    for (int s = 0; s < n_steps; ++s) {
+      store(0, R);
+      __syncthreads();
+      load_issue(R);
+      compute(0);
+      cursor_advance();
+      __syncthreads();
+    }
+    conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+    return;
+  }
 
   // Pipeline: LDS double-buffered, two register sets; the loads of tile s+2 are issued inside the MFMA phase of
   // tile s, whose basic block also splits / writes tile s+1.
@@ -438,6 +463,7 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
     case 3: return launch_fast<FCfg<64, 128, 32, 64>>(p, wpl, stream);
     case 4: return launch_fast<FCfg<64, 64, 32, 32>>(p, wpl, stream);
     case 5: return launch_fast<FCfg<128, 32, 32, 32>>(p, wpl, stream);
+    case 6: return launch_fast<FCfg<128, 128, 64, 64, 1>>(p, wpl, stream);  // single LDS stage, 3 workgroups / CU
     default: return 0;
   }
 }

@@ -19,7 +19,7 @@ def main():
     out = torch.empty(M, N, device=dev)
     prec = _lib.PREC_FP32 if "--fp32" in sys.argv else _lib.PREC_BF16X3
     op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
-                    precision=prec, tile=1)
+                    precision=prec, tile=int(os.environ.get("SRN_TILE", "1")))
     stop = False
 
     def watch():

@@ -28,7 +28,7 @@ def main():
     for K in ks:
         x = torch.randn(M, K, generator=g).to(dev)
         w = torch.randn(N, K, generator=g).to(dev)
-        for tile in (0, 1, 2, 4):
+        for tile in (0, 1, 2, 4, 6):
             op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
                             precision=prec, tile=tile)
             if planes:
