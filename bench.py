@@ -113,7 +113,7 @@ def main():
         mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"],
                               g["ref_logmel"], g["ref_midi"], g["ref_lft"], n_timesteps=N_EULER, noise=g["z"])
         wave = voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))  # inference() squeezes B == 1
-        return gather_waveforms(wave, dst=0) if world > 1 else wave
+        return gather_waveforms(wave, dst=0, uniform=True) if world > 1 else wave
 
     def sync():
         if world > 1:

@@ -16,18 +16,29 @@ def shard_range(n_items, rank, world_size):
     return start, start + q + (1 if rank < r else 0)
 
 
-def gather_waveforms(wave, n_samples=None, dst=0, group=None):
+def gather_waveforms(wave, n_samples=None, dst=0, group=None, uniform=False):
     """Gather per-rank waveform batches on rank `dst`.
 
     wave: (B_local, N_local) float tensor (padded); n_samples: (B_local,) int64 valid lengths or None.
     Returns on dst: (list of (B_r, N_r) tensors, list of (B_r,) length tensors) in rank order; elsewhere None.
-    Variable batch / length per rank is handled by first all-gathering the shapes, then padding to the max."""
+    Variable batch / length per rank is handled by first all-gathering the shapes, then padding to the max.
+    uniform=True: the caller guarantees the same (B, N) and full lengths on every rank (fixed-shape serving, the
+    benchmark): ONE collective, no shape exchange and no host synchronisation, so the host keeps running ahead of
+    the GPU into the next batch."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         ns = n_samples if n_samples is not None else torch.full((wave.shape[0],), wave.shape[1], dtype=torch.int64)
         return [wave], [ns.cpu()]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = wave.device
+    if uniform:
+        wave = wave.contiguous()
+        bufs = [torch.empty_like(wave) for _ in range(world)] if rank == dst else None
+        dist.gather(wave, bufs, dst=dst, group=group)
+        if rank != dst:
+            return None
+        full = torch.full((wave.shape[0],), wave.shape[1], dtype=torch.int64)
+        return bufs, [full.clone() for _ in range(world)]
     if n_samples is None:
         n_samples = torch.full((wave.shape[0],), wave.shape[1], dtype=torch.int64)
     shape = torch.tensor([wave.shape[0], wave.shape[1]], dtype=torch.int64, device=dev)
