@@ -40,7 +40,7 @@ __device__ __forceinline__ void group_stats(const float* __restrict__ partials, 
   __syncthreads();
 }
 
-constexpr int GN_ROWS = 32;  // rows per workgroup
+constexpr int GN_ROWS = 8;  // rows per workgroup (small: every workgroup first re-reduces the group statistics, more of them overlap that prefix)
 
 __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ partials,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------------
 // One wavefront per frame; C <= 1024 and C % 4 == 0 (up to MAXV float4 per lane).
-constexpr int TAIL_ROWS = 32;
+constexpr int TAIL_ROWS = 8;
 constexpr int MAXV = 4;
 
 __global__ __launch_bounds__(256) void resblock_tail_kernel(
