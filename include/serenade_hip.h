@@ -107,6 +107,11 @@ typedef struct SrnConvParams {
   void* ws; int64_t ws_bytes;
   const void* w_hi; const void* w_lo;
   float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */
+  /* Transposed tail, or out_tr == NULL: GEMM columns c >= out_tr_col0 (a multiple of 32) are written to
+   * out_tr[zb][c - out_tr_col0][t] (row stride ld_out_tr, batch stride out_tr_bs) INSTEAD of `out`.  The QKV
+   * projection writes V^T with it, so P.V (transformer.py:292-301) contracts k-major rows like every other GEMM and
+   * no transpose pass runs.  Plain epilogue only (no GEGLU / residual / post op / row stride / heads). */
+  float* out_tr; int64_t out_tr_bs; int32_t ld_out_tr; int32_t out_tr_col0;
 } SrnConvParams;
 
 int srn_abi_version(void);

@@ -34,6 +34,7 @@ class SrnConvParams(ctypes.Structure):
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ld_out", c_int32),
         ("precision", c_int32), ("no_halo", c_int32), ("ws", c_void_p), ("ws_bytes", c_int64),
         ("w_hi", c_void_p), ("w_lo", c_void_p), ("gn_partials", c_void_p),
+        ("out_tr", c_void_p), ("out_tr_bs", c_int64), ("ld_out_tr", c_int32), ("out_tr_col0", c_int32),
     ]
 
 

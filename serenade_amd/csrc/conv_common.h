@@ -112,6 +112,32 @@ __device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x1
         if (GEGLU) bias_g = p.bias[ncol + 32];
       }
       col_ok = col_ok && ocol < p.N_out;
+      if constexpr (!GEGLU && !RES) {
+        if (p.out_tr != nullptr && nc0 >= p.out_tr_col0) {
+          // transposed tail (V^T of the QKV projection): the lane's 4 consecutive rows of one column are 16
+          // contiguous bytes of out_tr[zb][col][t]
+          float* t_u = p.out_tr + (int64_t)zb * p.out_tr_bs + (int64_t)(nc0 - p.out_tr_col0) * p.ld_out_tr + tm;
+          const unsigned t_v = (unsigned)li * (unsigned)p.ld_out_tr + 4 * lh;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int trow = tm + 8 * gq + 4 * lh;
+            float4 v4;
+            v4.x = (rows_live || trow + 0 < len_out) ? acc[m][n][4 * gq + 0] * alpha + bias_v : 0.f;
+            v4.y = (rows_live || trow + 1 < len_out) ? acc[m][n][4 * gq + 1] * alpha + bias_v : 0.f;
+            v4.z = (rows_live || trow + 2 < len_out) ? acc[m][n][4 * gq + 2] * alpha + bias_v : 0.f;
+            v4.w = (rows_live || trow + 3 < len_out) ? acc[m][n][4 * gq + 3] * alpha + bias_v : 0.f;
+            float* dst = t_u + 8 * gq + t_v;
+            if (col_ok && trow + 3 < p.T_out) {
+              *reinterpret_cast<float4*>(dst) = v4;
+            } else if (col_ok) {
+              if (trow + 0 < p.T_out) dst[0] = v4.x;
+              if (trow + 1 < p.T_out) dst[1] = v4.y;
+              if (trow + 2 < p.T_out) dst[2] = v4.z;
+            }
+          }
+          continue;
+        }
+      }
       const bool interior = rows_in && nc0 + 32 <= p.N && oc0 + 32 <= p.N_out;
       // wave-uniform bases at sub-tile row 0 / column 0 and the per-lane, row-independent offsets
       float* o_u = out + orow0 * p.ld_out + oc0;

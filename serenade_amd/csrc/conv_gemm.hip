@@ -531,6 +531,12 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
     SRN_CHECK_ARG(p.N % 64 == 0 && p.res_mode == SRN_RES_NONE && p.res2 == nullptr && p.post == SRN_POST_NONE,
                   "conv_gemm: GEGLU needs N %% 64 == 0 and no residual / post op");
   if (p.res_mode != SRN_RES_NONE) SRN_CHECK_ARG(p.res != nullptr, "conv_gemm: res_mode set but res is null");
+  if (p.out_tr)
+    SRN_CHECK_ARG(!p.geglu && p.res_mode == SRN_RES_NONE && p.res2 == nullptr && p.post == SRN_POST_NONE &&
+                      p.out_t_stride == 1 && p.out_t_off == 0 && p.n_head == 1 && p.gn_partials == nullptr &&
+                      p.out_tr_col0 >= 0 && p.out_tr_col0 % 32 == 0 && p.ld_out_tr % 4 == 0 && p.ld_out_tr >= p.T_out &&
+                      (reinterpret_cast<uintptr_t>(p.out_tr) & 15) == 0 && p.out_tr_bs % 4 == 0,
+                  "conv_gemm: out_tr needs the plain epilogue, col0 %% 32 == 0 and a 16-byte aligned V^T with ld %% 4 == 0");
   if (p.gn_partials) SRN_CHECK_ARG(p.N % 32 == 0 && !p.geglu, "conv_gemm: gn_partials needs N %% 32 == 0");
   if (p.pad_reflect) {
     for (int i = 0; i < p.n_taps; ++i)

@@ -322,8 +322,9 @@ class DecoderPlan:
             T, ln = Ts[lvl], self.lens[lvl]
             Tp = _rup(T, 32)
             ol.append(ops.layernorm_op(X, t["ln1_w"], t["ln1_b"], bufN, B * T, C))
-            ol.append(conv(bufN, C, T, t["qkv_w"], None, qkv, 3 * inner, T, [0]))
-            ol.append(ops.transpose_op((qkv, 2 * inner), Vt[T], B, T, inner, T * 3 * inner, 3 * inner, inner * Tp, Tp))
+            # q | k row-major into qkv; the v third goes straight to V^T (transposed tail of the epilogue)
+            ol.append(conv(bufN, C, T, t["qkv_w"], None, qkv, 3 * inner, T, [0], out_tr=Vt[T], out_tr_col0=2 * inner,
+                           out_tr_bs=inner * Tp, ld_out_tr=Tp))
             # S = Q K^T / sqrt(d)   (batched over B x heads)
             ol.append(ConvOp(in0=qkv, w=(qkv, inner), out=S, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=hd, N=T,
                              in0_bs=T * 3 * inner, in0_hs=hd, ld_in0=3 * inner, w_bs=T * 3 * inner, w_hs=hd,

@@ -56,7 +56,8 @@ class ConvOp:
                  bias=None, len_in=None, len_out=None, in_stride=1, reflect=False, pro_act=ACT_NONE, pro_slope=0.0,
                  alpha=1.0, beta=0.0, geglu=False, res=None, res_mode=RES_NONE, res_bs=0, res_hs=0, ld_res=0, res2=None,
                  res2_bs=0, ld_res2=0, post=POST_NONE, post_div=1.0, out_bs=0, out_hs=0, out_t_stride=1, out_t_off=0,
-                 gn_partials=None, N_out=0, tile=0, precision=None, no_halo=False):
+                 gn_partials=None, N_out=0, tile=0, precision=None, no_halo=False, out_tr=None, out_tr_bs=0,
+                 ld_out_tr=0, out_tr_col0=0):
         p = SrnConvParams()
         p.n_batch, p.n_head, p.T_in, p.T_out = int(n_batch), int(n_head), int(T_in), int(T_out)
         p.C_in, p.C_in0, p.C_w, p.N, p.N_out = int(C_in), int(C_in0), int(C_w), int(N), int(N_out)
@@ -77,6 +78,7 @@ class ConvOp:
         p.res2, p.res2_bs, p.ld_res2 = _ptr(res2), int(res2_bs), int(ld_res2)
         p.out, p.out_bs, p.out_hs, p.ld_out = _ptr(out), int(out_bs), int(out_hs), int(ld_out)
         p.gn_partials = _ptr(gn_partials)
+        p.out_tr, p.out_tr_bs, p.ld_out_tr, p.out_tr_col0 = _ptr(out_tr), int(out_tr_bs), int(ld_out_tr), int(out_tr_col0)
         p.precision = int(DEFAULT_PRECISION if precision is None else precision)
         p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 tiled kernels only, 2 force halo, 3 generic kernel only, 4 force strip
         self.p = p

@@ -114,7 +114,15 @@ def emul_conv(kw):
             elif g("post", 0) == _lib.POST_LEAKY:
                 val = F.leaky_relu(val, g("post_div", 1.0))
             oidx = o_out + zb * g("out_bs", 0) + zh * g("out_hs", 0) + (t * ots + oto).unsqueeze(1) * g("ld_out") + cols
-            out[oidx] = val
+            if g("out_tr") is not None:  # transposed tail: columns >= col0 go to out_tr[zb][c - col0][t] instead
+                c0 = g("out_tr_col0", 0)
+                assert c0 % 32 == 0 and nh == 1 and ots == 1 and not geglu
+                otr, o_otr = _flat(g("out_tr"))
+                tidx = o_otr + zb * g("out_tr_bs", 0) + (cols[:, c0:] - c0) * g("ld_out_tr") + t.unsqueeze(1)
+                otr[tidx] = val[:, c0:]
+                out[oidx[:, :c0]] = val[:, :c0]
+            else:
+                out[oidx] = val
             if gnp is not None:
                 mt, nt = (T_out + 31) // 32, N // 32
                 pad = torch.zeros(mt * 32, nt * 32)

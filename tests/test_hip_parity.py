@@ -540,6 +540,25 @@ def test_training_forward_values_golden(dev, model, golden):
     assert abs(ret["cfm_loss"].item() / float(g["cfm_loss"]) - 1) < 1e-3
 
 
+def test_transposed_tail_epilogue(dev):
+    """QKV projection: columns >= out_tr_col0 land in out_tr[b][c - col0][t] (V^T), the rest row-major in out"""
+    B, Tn, K, N, c0 = 2, 203, 64, 192, 128
+    Tp = 224
+    kw = dict(in0=rnd(B, Tn, K, seed=41), w=rnd(N, K, seed=42), bias=rnd(N, seed=43), out=torch.zeros(B, Tn, N),
+              n_batch=B, T_in=Tn, T_out=Tn, C_in=K, N=N, in0_bs=Tn * K, ld_in0=K, ldw=K, out_bs=Tn * N, ld_out=N,
+              out_tr=torch.zeros(B, N - c0, Tp), out_tr_col0=c0, out_tr_bs=(N - c0) * Tp, ld_out_tr=Tp,
+              len_out=torch.tensor([203, 90], dtype=torch.int32))
+    run_conv_both(dev, kw, tiles=(0, 1, 3, 4))
+    m = Mirror(dev)
+    g = {k: m(v) for k, v in kw.items()}
+    ops.ConvOp(**g)()
+    ref = kw["in0"] @ kw["w"].t() + kw["bias"]
+    ref[1, 90:] = 0
+    assert nerr(g["out"][:, :, :c0], ref[:, :, :c0]) < KTOL.k and g["out"][:, :, c0:].abs().max().item() == 0
+    assert nerr(g["out_tr"][:, :, :Tn], ref[:, :, c0:].transpose(1, 2)) < KTOL.k
+    assert g["out_tr"][:, :, Tn:].abs().max().item() == 0  # pad columns are never written
+
+
 def test_hipgraph_replay_is_bitwise_the_eager_run(dev, model, voc):
     """ops.set_graphs(True): the plans (Euler loop, HiFi-GAN) replay as captured hipGraphs -- same launches, same bits"""
     d = synth_inputs(2, 72, T_ref=24, seed=77, lengths=[72, 50])
