@@ -21,7 +21,7 @@ def sig(k):
             k.get("in_stride", 1), bool(k.get("gn_partials") is not None), k.get("pro_act", 0))
 
 
-def time_ops(oplist, reps=5):
+def time_ops(oplist, reps=20):
     agg = collections.OrderedDict()
     for op in oplist:
         if not isinstance(op, ops.ConvOp):
