@@ -90,6 +90,16 @@ __device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x1
   const float alpha = p.alpha;
   const int res_mode = RES ? p.res_mode : SRN_RES_NONE;
   const int post = RES ? p.post : SRN_POST_NONE;
+  // bias of every column block up front: `bias` may alias `out` as far as the compiler knows, so a load inside the
+  // sub-tile loop cannot move above the previous sub-tile's stores and each sub-tile would start with a round trip
+  float bias_all[NT], bias_gate[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int ncol = n0 + wn0 + n * 32 + li;
+    const bool okc = p.bias != nullptr && ncol < p.N;
+    bias_all[n] = okc ? p.bias[ncol] : 0.f;
+    bias_gate[n] = (GEGLU && okc && ncol + 32 < p.N) ? p.bias[ncol + 32] : 0.f;
+  }
 
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -105,12 +115,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const SrnConvParams& p, f32x1
       const int oc0 = GEGLU ? (nc0 >> 6) * 32 : nc0;
       const int ncol = nc0 + li;
       const int ocol = oc0 + li;
-      float bias_v = 0.f, bias_g = 0.f;
+      const float bias_v = bias_all[n], bias_g = bias_gate[n];
       bool col_ok = ncol < p.N;
-      if (p.bias && col_ok) {
-        bias_v = p.bias[ncol];
-        if (GEGLU) bias_g = p.bias[ncol + 32];
-      }
       col_ok = col_ok && ocol < p.N_out;
       if constexpr (!GEGLU && !RES) {
         if (p.out_tr != nullptr && nc0 >= p.out_tr_col0) {
