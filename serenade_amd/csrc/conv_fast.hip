@@ -42,14 +42,16 @@ __device__ __forceinline__ void split_pair(const float a, const float b, unsigne
 
 // NSTAGE: LDS stages.  2: tile s+1 is split / written while tile s is multiplied.  1: the two phases alternate
 // between barriers inside a workgroup and a third co-resident workgroup (32 KB each) supplies the overlap.
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_ = 2>
+// PREC: 1 = split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per product), 0 = exact fp32 (v_mfma_f32_32x32x2_f32); the fp32
+// LDS image is [rows][32 floats + 4 pad] (144-B rows: conflict-free ds_read_b128 of 16 rows), A then B.
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_ = 2, int PREC_ = 1>
 struct FCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, PREC = PREC_;
   static constexpr int MT = WM / 32, NT = WN / 32;
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
   static constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per step
-  static constexpr int STAGE = (BM + BN) * 128;          // [A_hi | A_lo | B_hi | B_lo], 64 B per tile row
+  static constexpr int STAGE = (BM + BN) * (PREC ? 128 : 144);  // split: [A_hi | A_lo | B_hi | B_lo], 64 B per row
   static constexpr int SMEM_BYTES = NSTAGE * STAGE;
   // workgroups per CU the kernel is compiled for (register budget 512 / waves per SIMD): three where the LDS allows
   static constexpr int MIN_BLOCKS = SMEM_BYTES * 3 <= 160 * 1024 ? 3 : 2;
@@ -185,6 +187,35 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     unsigned char* sa_lo = sa_hi + BM * 64;
     unsigned char* sb_hi = sa_lo + BM * 64;
     unsigned char* sb_lo = sb_hi + BN * 64;
+    if constexpr (C::PREC == 0) {
+      float* a32 = reinterpret_cast<float*>(smem_f + stage * C::STAGE) + lrow * 36 + c4 * 4;
+      float* b32 = a32 + BM * 36;
+#pragma unroll
+      for (int i = 0; i < C::A_LD; ++i) {
+        float4 v = R.pa[i];
+        if constexpr (ACT == SRN_ACT_LEAKY) {
+          v.x = v.x > 0.f ? v.x : v.x * pro_slope;
+          v.y = v.y > 0.f ? v.y : v.y * pro_slope;
+          v.z = v.z > 0.f ? v.z : v.z * pro_slope;
+          v.w = v.w > 0.f ? v.w : v.w * pro_slope;
+        } else if constexpr (ACT < 0) {
+          v.x = srn_act(v.x, pro_act, pro_slope);
+          v.y = srn_act(v.y, pro_act, pro_slope);
+          v.z = srn_act(v.z, pro_act, pro_slope);
+          v.w = srn_act(v.w, pro_act, pro_slope);
+        } else {
+          asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));  // keep the staged set out of scratch
+        }
+        *reinterpret_cast<float4*>(a32 + i * 32 * 36) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < C::B_LD; ++i) {
+        float4 v = R.pb[i];
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        *reinterpret_cast<float4*>(b32 + i * 32 * 36) = v;
+      }
+      return;
+    }
     if constexpr (APL) {
       unsigned char* dsta = (c4 < 4 ? sa_hi : sa_lo) + stb_off;
 #pragma unroll
@@ -255,6 +286,35 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     const unsigned char* sa_lo = sa_hi + BM * 64;
     const unsigned char* sb_hi = sa_lo + BM * 64;
     const unsigned char* sb_lo = sb_hi + BN * 64;
+    if constexpr (C::PREC == 0) {
+      const float* a = reinterpret_cast<const float*>(smem_f + stage * C::STAGE) + (wm0 + li) * 36 + 4 * lh;
+      const float* b = reinterpret_cast<const float*>(smem_f + stage * C::STAGE) + (BM + wn0 + li) * 36 + 4 * lh;
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        float4 af[MT], bf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(a + m * 32 * 36 + kk * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[n] = *reinterpret_cast<const float4*>(b + n * 32 * 36 + kk * 8);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
 #ifdef SRN_DBG_HALFLDS  // timing-only experiment (wrong arithmetic): the second k16 half re-reads nothing from LDS
@@ -320,17 +380,19 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     compute(cs);
     store(ss, Rs);
     load_issue(Rl);
-    constexpr int N_MFMA = MT * NT * 6;
+    constexpr bool F32 = C::PREC == 0;
+    constexpr int N_MFMA = MT * NT * (F32 ? 16 : 6);
     constexpr int N_DSR = (MT + NT) * 4;
     constexpr int N_LD = C::A_LD + C::B_LD;
-    constexpr int N_VALU = (APL ? 0 : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18)) + (WPL ? 0 : C::B_LD * 10) + N_LD;
-    constexpr int N_DSW = (APL ? C::A_LD : C::A_LD * 2) + (WPL ? C::B_LD : C::B_LD * 2);
+    constexpr int N_VALU = F32 ? C::A_LD * (ACT == SRN_ACT_NONE ? 0 : 8) + N_LD
+                               : (APL ? 0 : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18)) + (WPL ? 0 : C::B_LD * 10) + N_LD;
+    constexpr int N_DSW = F32 ? C::A_LD + C::B_LD : (APL ? C::A_LD : C::A_LD * 2) + (WPL ? C::B_LD : C::B_LD * 2);
     constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
-    __builtin_amdgcn_sched_group_barrier(0x100, (MT + NT) * 2, 0);  // fragments of the first k16 half
+    __builtin_amdgcn_sched_group_barrier(0x100, F32 ? (MT + NT) : (MT + NT) * 2, 0);  // fragments of the first k slice
 #pragma unroll
     for (int i = 0; i < N_MFMA; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < N_DSR - (MT + NT) * 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < N_DSR - (F32 ? (MT + NT) : (MT + NT) * 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       if (i * N_LD / N_MFMA != (i + 1) * N_LD / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
       if (i * N_DSW / N_MFMA != (i + 1) * N_DSW / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -435,7 +497,8 @@ int launch_fast3(const SrnConvParams& p, hipStream_t stream) {
 
 template <class C, int ACT>
 int launch_fast2(const SrnConvParams& p, bool wpl, hipStream_t stream) {
-  return wpl ? launch_fast3<C, ACT, true>(p, stream) : launch_fast3<C, ACT, false>(p, stream);
+  if constexpr (C::PREC == 0) return launch_fast3<C, ACT, false>(p, stream);  // fp32: plain weight rows
+  else return wpl ? launch_fast3<C, ACT, true>(p, stream) : launch_fast3<C, ACT, false>(p, stream);
 }
 
 template <class C>
@@ -450,12 +513,23 @@ int launch_fast(const SrnConvParams& p, bool wpl, hipStream_t stream) {
 // Returns 1 if the launch was handled, 0 if the shape is not eligible (caller falls back to the generic kernel),
 // < 0 on error.  `p` has been validated and defaulted by srn_conv_gemm.
 int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
-  if (p.precision != SRN_PREC_BF16X3 || p.w_nmajor) return 0;
+  if (p.w_nmajor) return 0;
   if (p.C_in % BK != 0 || p.C_in0 % BK != 0) return 0;
-  const bool wpl = p.w_hi != nullptr && p.w_bs == 0 && p.w_hs == 0;
+  const bool f32 = p.precision != SRN_PREC_BF16X3;
+  const bool wpl = !f32 && p.w_hi != nullptr && p.w_bs == 0 && p.w_hs == 0;
   if (!wpl) {
     // fp32 B rows walked contiguously over (tap, channel): needs the packed [tap][C_in] row layout, all of it live
     if (p.C_w != p.C_in || p.ldw < p.n_taps * p.C_in) return 0;
+  }
+  if (f32) {
+    switch (tile) {
+      case 1: return launch_fast<FCfg<128, 128, 64, 64, 2, 0>>(p, false, stream);
+      case 2: return launch_fast<FCfg<128, 64, 32, 64, 2, 0>>(p, false, stream);
+      case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 0>>(p, false, stream);
+      case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 0>>(p, false, stream);
+      case 5: return launch_fast<FCfg<128, 32, 32, 32, 2, 0>>(p, false, stream);
+      default: return 0;
+    }
   }
   switch (tile) {
     case 1: return launch_fast<FCfg<128, 128, 64, 64>>(p, wpl, stream);

@@ -85,7 +85,7 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     tol = KTOL.k if tol is None else tol
     # split-bf16 has three kernels behind the one entry point: conv_fast (regular shapes; auto), the LDS-DMA planes
     # pipeline (workspace attached) and the generic conv_gemm kernel (no_halo=3 forces it)
-    variants = ("auto", "planes", "generic") if serenade_amd.get_precision() == "bf16x3" else ("auto",)
+    variants = ("auto", "planes", "generic") if serenade_amd.get_precision() == "bf16x3" else ("auto", "generic")
     for tile, variant in [(t, u) for t in tiles for u in variants]:
         use_ws = variant == "planes"
         cpu = {}
