@@ -8,7 +8,16 @@
 //   * static weights arrive pre-split (bf16 hi|lo planes, one 128-B line per row per 32-channel step, packed at
 //     load time by ops.weight_planes): 16-B loads go to LDS untouched, only activations are split in the loop;
 //   * the split itself is 2.5 VALU per element (v_cvt_pk_bf16_f32 on pairs, v_pk_add_f32).
-// Shapes it does not take (ragged channels, n-major B, fp32 mode) stay on conv_gemm.hip.
+// The same loop runs the exact-fp32 mode (FCfg<..., PREC = 0>: fp32 LDS image, v_mfma_f32_32x32x2_f32; 131 TFLOP/s
+// sustained on 10240 x 2048 x 2048 = 0.83 of the fp32 MFMA peak).  Shapes it does not take (ragged channels, n-major B)
+// stay on conv_gemm.hip.
+//
+// Measured and NOT adopted (A/B or timing-only builds, 10240 x 2048 x 2048 split-bf16, 351 TFLOP/s sustained baseline):
+// v_mfma_f32_16x16x32_bf16 issue +4 %; A operand pre-split as well +2.7 %; half the LDS fragment reads +0 %; one LDS
+// stage at three workgroups per CU -1 %; 128-B pad between the B planes (no ds_write_b128 bank conflicts) -2.7 %;
+// persistent workgroups prefetching the next tile before the epilogue -17 % (spills); 256 x 256 tile on 8 waves
+// +6.5 % at K = 2048 but +1 % at K = 512, where every wide-N GEMM of the path lives.  The card runs the loop at its
+// 1370 W cap (1.93 GHz).
 #include <hip/hip_runtime.h>
 
 #include "common.h"

@@ -14,7 +14,7 @@ from serenade_amd import _lib, ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    M, N, K = 10240, 2048, 2048
+    M, N, K = (int(os.environ.get(k, d)) for k, d in (("SRN_M", 10240), ("SRN_N", 2048), ("SRN_K", 2048)))
     x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
     out = torch.empty(M, N, device=dev)
     prec = _lib.PREC_FP32 if "--fp32" in sys.argv else _lib.PREC_BF16X3
