@@ -4,7 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
-import sys
+
 
 import pytest
 

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from oracle import serenade_oracle as O
 from serenade_amd import _lib, models, ops, vocoder
-from serenade_amd.utils.synth import HIFIGAN_PARAMS, SERENADE_PARAMS, fill_state_dict, synth_inputs
+from serenade_amd.utils.synth import SERENADE_PARAMS, fill_state_dict, synth_inputs
 from tests import _emulator
 from tests._weights import hifigan_weights, serenade_weights, sub
 
