@@ -93,7 +93,7 @@ def main():
         ops.DEFAULT_PRECISION = _lib.PREC_BF16X3
     dev = torch.device("cuda:0")
     model, voc, sd, gsd = bench.build_models(dev)
-    B, T, Tr = bench.B_PER_GPU, bench.T_SRC, bench.T_REF
+    B, T, Tr = (int(os.environ.get(k, d)) for k, d in (("SRN_B", bench.B_PER_GPU), ("SRN_T", bench.T_SRC), ("SRN_TREF", bench.T_REF)))
     from serenade_amd.utils.synth import synth_inputs
     d = synth_inputs(B, T, T_ref=Tr, seed=1235)
     g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
