@@ -127,6 +127,13 @@ _WPLANES = {}  # (data_ptr, shape, taps, C_in) -> (hi, lo) bf16 weight planes, s
 _WS = {}       # device -> shared uint8 workspace
 
 
+def clear_caches():
+    """Drop the weight-plane cache and the shared workspaces (long-running services that load many checkpoints).
+    Ops already built keep their own references, so existing plans stay valid."""
+    _WPLANES.clear()
+    _WS.clear()
+
+
 def weight_planes(w, N, n_taps, C_in, ldw):
     """fp32 packed weights [N][n_taps * C_in] -> bf16 planes [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32],
     hi = bf16(w), lo = bf16(w - hi) (round-to-nearest-even, the same split the kernels apply to activations)."""
