@@ -46,8 +46,10 @@ enum {
 };
 
 /*
- * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors, computed with the exact-fp32
- * MFMA (v_mfma_f32_32x32x2_f32):
+ * Generalised implicit-GEMM "conv1d" on channels-last fp32 tensors.  Arithmetic of the contraction per
+ * `precision`: SRN_PREC_FP32 = exact fp32 on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain, the
+ * reference's precision); SRN_PREC_BF16X3 = every fp32 operand split into (hi, lo) bf16, three
+ * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (~2^-17 relative per product):
  *
  *   out[z, t*out_t_stride + out_t_off, n] = epilogue( alpha * sum_{tap, c} w[n, tap*C_in + c] *
  *                                  act( in[z, t*in_stride + tap_off[tap], c] ) + bias[n] )
@@ -100,10 +102,9 @@ typedef struct SrnConvParams {
   int32_t no_halo;    /* kernel selection behind this entry point (testing / A-B timing): 0 = automatic, 1 = tiled kernels
                        * only (no halo, no strip), 2 = halo kernel whenever eligible, 3 = generic conv_gemm kernel only,
                        * 4 = strip kernel whenever eligible */
-  /* split-bf16 fast path (conv_planes.hip): an HBM workspace into which the operands are split once into (hi, lo)
-   * bf16 planes and from which the GEMM streams them with LDS-DMA.  ws == NULL selects the in-kernel split path.
-   * w_hi: weights already split at load time, bf16 [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32] (NULL: split per
-   * call; w_lo is reserved). */
+  /* ws / ws_bytes / w_lo: reserved, must be NULL / 0 (kept so that the struct layout of ABI version 1 is unchanged).
+   * w_hi (SRN_PREC_BF16X3 only): the static weights already split at load time, bf16
+   * [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32]; NULL: the kernel splits the fp32 rows of `w` per call. */
   void* ws; int64_t ws_bytes;
   const void* w_hi; const void* w_lo;
   float* gn_partials; /* or NULL: [zb][ceil(T_out/32)][N/32][2] per-32x32-tile (sum, sumsq) of the stored values */

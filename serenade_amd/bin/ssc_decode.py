@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""`serenade-decode` on MI355X — same command line, inputs and outputs as serenade/bin/ssc_decode.py:190-455:
+"""`serenade-decode` for MI355X.
+
+Drop-in for the reference's decode entry point (interface: serenade/bin/ssc_decode.py:192-253 flags,
+:361-366/:395-400/:444-455 output files).  The command line, the files read and the files written are the
+reference's; the program itself is organised as a small job object around the HIP-backed model and vocoder:
 
     python -m serenade_amd.bin.ssc_decode --dumpdir DIR --stats stats.joblib --ref-dict refs.json \
         --outdir OUT --checkpoint checkpoint.pkl [--config config.yml] [--verbose 1]
 
-writes `{utt}_gt.wav`, `00_{style}_reference.wav`, `{utt}_{style}.wav` (PCM_16) and `{utt}_{style}.h5["lf0"]`.
-The model and vocoder are the HIP-backed classes of serenade_amd; feature files may be .h5 (h5py) or .npz.
+Per source utterance `U` and reference style `S` it writes `U_gt.wav`, `00_S_reference.wav`, `U_S.wav` (16-bit
+PCM) and the transposed F0 contour as dataset `lf0` of `U_S.h5` (`.npz` when the dump is `.npz`).  Utterances are
+converted one at a time (B = 1) on purpose: GroupNorm statistics of the estimator run over an utterance's padded
+length (decoder.py:71-77), so padding utterances into a common batch would change their output.  With
+`torchrun --nproc-per-node N` the utterance list is split contiguously over the ranks (one GPU each).
 """
 import argparse
 import glob
@@ -19,135 +26,177 @@ import torch
 import yaml
 
 import serenade_amd.models
+from serenade_amd import parallel
 from serenade_amd.datasets import FeatsDataset
 from serenade_amd.utils.f0 import linear_midi_shift
 from serenade_amd.utils.io import read_feats, write_feats, write_wav_pcm16
 from serenade_amd.vocoder import Vocoder
 
+STYLES = ("Breathy", "Falsetto", "Pharyngeal", "Mixed_Voice")
+
+
+def _sibling_dump(dirname):
+    """the other half of a two-way dump split (`dump.1` <-> `dump.2`), or None"""
+    for a, b in (("dump.2", "dump.1"), ("dump.1", "dump.2")):
+        if a in dirname:
+            return dirname.replace(a, b)
+    return None
+
 
 def get_random_ref_style(dumpdir, utt_id, ext="h5"):
-    """One random reference file per singing style for the speaker of `utt_id` (ssc_decode.py:157-187)."""
-    dirname = dumpdir
-    ln, spk = utt_id.split("_")[:2]
-    ref_dict = {}
-    for style in ["Breathy", "Falsetto", "Pharyngeal", "Mixed_Voice"]:
-        name = f"{ln}_{spk}_*_{style}_Group_*.{ext}"
-        files = glob.glob(os.path.join(dirname, name))
-        if not files:
-            other = None
-            if "dump.2" in dirname:
-                other = dirname.replace("dump.2", "dump.1")
-            elif "dump.1" in dirname:
-                other = dirname.replace("dump.1", "dump.2")
-            if other is not None:
-                files = glob.glob(os.path.join(other, name))
-        if files:
-            ref_dict[style] = np.random.choice(files)
-    logging.info(f"Using reference styles: {ref_dict}")
-    return ref_dict
+    """{style: feature file} with one randomly drawn prompt per singing style, taken from the same language and
+    singer as `utt_id` (file names are `<lang>_<singer>_<song>_<style>_Group_<n>`); styles without any candidate in
+    `dumpdir` or its sibling split are left out."""
+    lang, singer = utt_id.split("_")[:2]
+    chosen = {}
+    for style in STYLES:
+        pattern = f"{lang}_{singer}_*_{style}_Group_*.{ext}"
+        found = glob.glob(os.path.join(dumpdir, pattern))
+        if not found and _sibling_dump(dumpdir) is not None:
+            found = glob.glob(os.path.join(_sibling_dump(dumpdir), pattern))
+        if found:
+            chosen[style] = np.random.choice(found)
+    logging.info(f"prompt per style: {chosen}")
+    return chosen
 
 
 def build_parser():
-    p = argparse.ArgumentParser(description="Decode with trained SSC model (See detail in bin/ssc_decode.py).")
+    p = argparse.ArgumentParser(description="Singing-style conversion of a feature dump with a trained Serenade "
+                                            "model and its vocoder (MI355X build).")
     p.add_argument("--config", default=None, type=str,
-                   help="yaml format configuration file. if not explicitly provided, it will be searched in the "
-                        "checkpoint directory. (default=None)")
+                   help="training configuration (YAML); defaults to config.yml beside --checkpoint")
     p.add_argument("--feats-scp", "--scp", default=None, type=str,
-                   help="kaldi-style feats.scp file. you need to specify either feats-scp or dumpdir.")
+                   help="Kaldi-style feats.scp listing the inputs (give exactly one of --feats-scp / --dumpdir)")
     p.add_argument("--dumpdir", default=None, type=str,
-                   help="directory including feature files. you need to specify either feats-scp or dumpdir.")
-    p.add_argument("--stats", type=str, required=True, help="stats file for target denormalization.")
-    p.add_argument("--ref-dict", type=str, default=None, help="yaml format file containing reference styles.")
-    p.add_argument("--outdir", type=str, required=True, help="directory to save generated speech.")
-    p.add_argument("--checkpoint", type=str, required=True, help="checkpoint file to be loaded.")
-    p.add_argument("--verbose", type=int, default=1, help="logging level. higher is more logging. (default=1)")
+                   help="directory of per-utterance feature files (give exactly one of --feats-scp / --dumpdir)")
+    p.add_argument("--stats", type=str, required=True,
+                   help="joblib file of the fitted feature scalers; its log-mel scaler de-normalises the output")
+    p.add_argument("--ref-dict", type=str, default=None,
+                   help="JSON map style -> prompt feature file; without it one prompt per style is drawn at random")
+    p.add_argument("--outdir", type=str, required=True, help="where the converted audio and F0 files go")
+    p.add_argument("--checkpoint", type=str, required=True, help="model checkpoint (its ['model'] entry is loaded)")
+    p.add_argument("--verbose", type=int, default=1, help="0: warnings only, 1: info, 2+: debug (default 1)")
     return p
+
+
+def _setup_logging(verbose):
+    level = logging.WARN if verbose <= 0 else logging.INFO if verbose == 1 else logging.DEBUG
+    logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    if verbose <= 0:
+        logging.warning("INFO and DEBUG messages are suppressed")
+
+
+class DecodeJob:
+    """Everything one decode run needs: merged config, scalers, vocoder, model, dataset."""
+
+    def __init__(self, args):
+        self.args = args
+        if torch.cuda.is_available():  # one process per GPU under torchrun; plain runs use device 0
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.device = torch.device("cpu")
+        cfg_path = args.config or os.path.join(os.path.dirname(args.checkpoint), "config.yml")
+        with open(cfg_path) as f:
+            self.config = yaml.load(f, Loader=yaml.Loader)
+        self.config.update(vars(args))  # command line wins, as in the reference (ssc_decode.py:287-289)
+        self.styles = None
+        if args.ref_dict is not None:
+            with open(args.ref_dict) as f:
+                self.styles = json.load(f)
+        else:
+            logging.info("no --ref-dict: drawing one random prompt per style")
+        for k, v in self.config.items():
+            logging.info(f"{k} = {v}")
+
+        from joblib import load
+        self.scaler = load(args.stats)
+        mel_scaler = self.scaler["logmel"]
+        self.config["trg_stats"] = {"mean": mel_scaler.mean_, "scale": mel_scaler.scale_}
+        voc = self.config["vocoder"]
+        self.vocoder = Vocoder(voc["checkpoint"], voc["config"], voc["stats"], self.device,
+                               trg_stats=self.config["trg_stats"])
+        if (args.feats_scp is None) == (args.dumpdir is None):
+            raise ValueError("Please specify either --dumpdir or --feats-scp.")
+        self.dataset = FeatsDataset(root_dir=args.dumpdir, scaler=self.scaler, score_type="est_lf0_score",
+                                    return_utt_id=True, allow_cache=self.config.get("allow_cache", False))
+        logging.info(f"{len(self.dataset)} utterances to convert")
+        cls = getattr(serenade_amd.models, self.config["model_type"])  # the reference's plugin lookup (:337)
+        self.model = cls(**self.config["model_params"])
+        self.model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"])
+        self.model = self.model.eval().to(self.device)
+        logging.info(f"model weights: {args.checkpoint}")
+        self.sr = self.config["sampling_rate"]
+        self.ext = os.path.splitext(self.dataset.audio_files[0])[1].lstrip(".")
+
+    # ---- tensors -------------------------------------------------------------------------------------------
+    def _t(self, a):
+        return torch.tensor(np.asarray(a), dtype=torch.float).to(self.device)
+
+    def _standard(self, a, key):
+        s = self.scaler[key]
+        return (a - s.mean_) / s.scale_
+
+    def _minmax(self, a, key):
+        s = self.scaler[key]
+        return (a - s.data_min_) / (s.data_max_ - s.data_min_)
+
+    def prompt(self, path):
+        """normalised prompt tensors + raw prompt audio / F0 of one reference feature file"""
+        raw = {k: read_feats(path, k) for k in ("hubert", "logmel", "loud", "wave", "est_lf0_score", "f0")}
+        cvec = self._t(self._standard(raw["hubert"], "hubert")).unsqueeze(0)
+        return dict(cvec=cvec, lens=torch.tensor([cvec.size(1)], dtype=torch.long),
+                    mel=self._t(self._standard(raw["logmel"], "logmel")).unsqueeze(0),
+                    score=self._t(self._minmax(raw["est_lf0_score"], "score")).view(1, -1, 1),
+                    loud=self._t(self._minmax(raw["loud"], "loud")).unsqueeze(0), wave=raw["wave"], f0=raw["f0"])
+
+    # ---- the loop ------------------------------------------------------------------------------------------
+    def convert(self, item):
+        """all styles of one source utterance; returns the number of converted frames"""
+        out = self.args.outdir
+        utt = item["utt_id"]
+        logging.info(f"utterance {utt}")
+        write_wav_pcm16(os.path.join(out, f"{utt}_gt.wav"), item["audio"], self.sr)
+        x = self._t(item["hubert"]).unsqueeze(0)
+        lengths = torch.tensor([x.shape[1]], dtype=torch.long)
+        score, loud = self._t(item["score"]).unsqueeze(0), self._t(item["loud"]).unsqueeze(0)
+        if self.styles is None:  # drawn once, for the first utterance, then kept (ssc_decode.py:375-376)
+            self.styles = get_random_ref_style(self.args.dumpdir, utt, self.ext)
+        done = 0
+        for style, path in self.styles.items():
+            if style in utt:  # a prompt of the utterance's own style would be a reconstruction
+                continue
+            logging.info(f"  style {style}")
+            ref = self.prompt(path)
+            write_wav_pcm16(os.path.join(out, f"00_{style}_reference.wav"), ref["wave"], self.sr)
+            # NB: linear_midi_shift edits item["lf0"] in place, so later styles start from the shifted contour --
+            # the reference behaves the same way (ssc_decode.py:424)
+            lf0 = linear_midi_shift(item["lf0"], ref["f0"])
+            mel = self.model.inference(x, lengths, score, loud, ref["cvec"], ref["lens"], ref["mel"], ref["score"],
+                                       ref["loud"])
+            wave, _ = self.vocoder.decode(mel.squeeze(0))
+            write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0.astype(np.float32))
+            write_wav_pcm16(os.path.join(out, f"{utt}_{style}.wav"), wave.cpu().numpy(), self.sr)
+            done += x.shape[1]
+        return done
+
+    def run(self):
+        rank, world = parallel.rank_world()
+        lo, hi = parallel.shard_range(len(self.dataset), rank, world)
+        frames, t0 = 0, time.time()
+        with torch.no_grad():
+            for i in range(lo, hi):
+                frames += self.convert(self.dataset[i])
+        dt = max(time.time() - t0, 1e-9)
+        logging.info(f"rank {rank}/{world}: {frames} frames in {dt:.2f} s = {frames / dt:.1f} frames/s")
+        return frames
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    fmt = "%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s"
-    level = logging.DEBUG if args.verbose > 1 else logging.INFO if args.verbose > 0 else logging.WARN
-    logging.basicConfig(level=level, format=fmt)
-    if args.verbose <= 0:
-        logging.warning("Skip DEBUG/INFO messages")
+    _setup_logging(args.verbose)
     os.makedirs(args.outdir, exist_ok=True)
-
-    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    if args.config is None:
-        args.config = os.path.join(os.path.dirname(args.checkpoint), "config.yml")
-    with open(args.config) as f:
-        config = yaml.load(f, Loader=yaml.Loader)
-    config.update(vars(args))
-    ref_dict = None
-    if args.ref_dict is not None:
-        with open(args.ref_dict, "r") as f:
-            ref_dict = json.load(f)
-    else:
-        logging.info("No reference dictionary provided, using random reference styles.")
-    for key, value in config.items():
-        logging.info(f"{key} = {value}")
-
-    from joblib import load
-    scaler = load(args.stats)
-    config["trg_stats"] = {"mean": scaler["logmel"].mean_, "scale": scaler["logmel"].scale_}
-    vocoder = Vocoder(config["vocoder"]["checkpoint"], config["vocoder"]["config"], config["vocoder"]["stats"], device,
-                      trg_stats=config["trg_stats"])
-    if (args.feats_scp is not None and args.dumpdir is not None) or (args.feats_scp is None and args.dumpdir is None):
-        raise ValueError("Please specify either --dumpdir or --feats-scp.")
-    dataset = FeatsDataset(root_dir=args.dumpdir, scaler=scaler, score_type="est_lf0_score", return_utt_id=True,
-                           allow_cache=config.get("allow_cache", False))
-    logging.info(f"The number of features to be decoded = {len(dataset)}.")
-
-    model_class = getattr(serenade_amd.models, config["model_type"])
-    model = model_class(**config["model_params"])
-    model.load_state_dict(torch.load(args.checkpoint, map_location="cpu")["model"])
-    model = model.eval().to(device)
-    logging.info(f"Loaded model parameters from {args.checkpoint}.")
-    sr = config["sampling_rate"]
-    fext = os.path.splitext(dataset.audio_files[0])[1].lstrip(".")
-
-    def dev(a, shape=None):
-        t = torch.tensor(np.asarray(a), dtype=torch.float).to(device)
-        return t.view(*shape) if shape is not None else t
-
-    n_frames, t_start = 0, time.time()
-    with torch.no_grad():
-        for batch in dataset:
-            utt_id = batch["utt_id"]
-            logging.info(f"Decoding {utt_id}")
-            lf0 = batch["lf0"]
-            write_wav_pcm16(os.path.join(args.outdir, f"{utt_id}_gt.wav"), batch["audio"], sr)
-            x = dev(batch["hubert"]).unsqueeze(0)
-            lengths = torch.tensor([x.shape[1]], dtype=torch.long)
-            scores = dev(batch["score"]).unsqueeze(0)
-            lfts = dev(batch["loud"]).unsqueeze(0)
-            if ref_dict is None:
-                ref_dict = get_random_ref_style(args.dumpdir, utt_id, fext)
-            for style, ref_path in ref_dict.items():
-                if style in utt_id:  # avoid reconstruction
-                    continue
-                logging.info(f"Processing reference style: {style}")
-                ref_cvec, ref_mel = read_feats(ref_path, "hubert"), read_feats(ref_path, "logmel")
-                ref_lft, ref_wave = read_feats(ref_path, "loud"), read_feats(ref_path, "wave")
-                ref_score, ref_lf0 = read_feats(ref_path, "est_lf0_score"), read_feats(ref_path, "f0")
-                write_wav_pcm16(os.path.join(args.outdir, f"00_{style}_reference.wav"), ref_wave, sr)
-                ref_cvec = dev((ref_cvec - scaler["hubert"].mean_) / scaler["hubert"].scale_).unsqueeze(0)
-                ref_mel = dev((ref_mel - scaler["logmel"].mean_) / scaler["logmel"].scale_).unsqueeze(0)
-                ref_lns = torch.tensor([ref_cvec.size(1)], dtype=torch.long)
-                ref_score = dev((ref_score - scaler["score"].data_min_) /
-                                (scaler["score"].data_max_ - scaler["score"].data_min_), (1, -1, 1))
-                ref_lft = dev((ref_lft - scaler["loud"].data_min_) /
-                              (scaler["loud"].data_max_ - scaler["loud"].data_min_)).unsqueeze(0)
-                shifted_lf0 = linear_midi_shift(lf0, ref_lf0)
-                mel_ = model.inference(x, lengths, scores, lfts, ref_cvec, ref_lns, ref_mel, ref_score, ref_lft)
-                wave, _ = vocoder.decode(mel_.squeeze(0))
-                outname = f"{utt_id}_{style}"
-                write_feats(os.path.join(args.outdir, f"{outname}.{fext}"), "lf0", shifted_lf0.astype(np.float32))
-                write_wav_pcm16(os.path.join(args.outdir, f"{outname}.wav"), wave.cpu().numpy(), sr)
-                n_frames += x.shape[1]
-    dt = time.time() - t_start
-    logging.info(f"Converted {n_frames} frames in {dt:.2f} s ({n_frames / max(dt, 1e-9):.1f} frames/s).")
+    DecodeJob(args).run()
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libserenade_hip.so")
-SOURCES = ["conv_gemm.hip", "conv_halo.hip", "conv_planes.hip", "conv_fast.hip", "conv_strip.hip", "norm_act.hip", "gst.hip", "api.cpp"]
+SOURCES = ["conv_gemm.hip", "conv_halo.hip", "conv_fast.hip", "conv_strip.hip", "norm_act.hip", "gst.hip", "api.cpp"]
 
 
 def _hipcc():
@@ -35,7 +35,6 @@ def build(force=False, verbose=True):
         obj = os.path.join(HERE, "build", src + ".o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
-        cmd += os.environ.get("SRN_EXTRA_CFLAGS", "").split()  # developer experiments (-D...)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "serenade_hip.h"
 
 void srn_set_error(const char* fmt, ...);
@@ -26,6 +28,24 @@ void srn_set_error(const char* fmt, ...);
   } while (0)
 
 #define SRN_CHECK_LAUNCH() SRN_CHECK_HIP(hipGetLastError())
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel.  One of these per kernel
+// instantiation (function-local static) remembers, per device and thread-safely, that the size has been granted,
+// so a process that moves from cuda:0 to cuda:1, or launches from several threads, still gets its LDS.
+// `bytes` must be the same on every call for one kernel (pass the kernel's maximum).
+struct SrnSmemAttr {
+  std::atomic<unsigned long long> done{0};
+  int ensure(const void* fn, int bytes) {
+    int dev = 0;
+    SRN_CHECK_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    const unsigned long long bit = tracked ? 1ull << dev : 0ull;
+    if (tracked && (done.load(std::memory_order_acquire) & bit)) return 0;
+    SRN_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+  }
+};
 
 // ---- device math --------------------------------------------------------------------------
 // Mish(x) = x * tanh(softplus(x)) (decoder.py:72,84).  tanh(log1p(e^x)) = n / (n + 2) with

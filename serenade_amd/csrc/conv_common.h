@@ -232,8 +232,6 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
 // implemented in conv_halo.hip: receptive-field ("halo") variant for stride-1 multi-tap convs in split-bf16.
 // Returns 1 if it handled the launch, 0 if the shape is not eligible, < 0 on error.
 int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);
-// implemented in conv_planes.hip: operands pre-split into bf16 planes in p.ws, LDS-DMA pipeline.  Same return codes.
-int srn_conv_planes_try(const SrnConvParams& p, int tile, hipStream_t stream);
 // implemented in conv_fast.hip: lean split-bf16 kernel for C_in % 32 == 0, k-major weights.  Same return codes.
 int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream);
 // implemented in conv_strip.hip: thin convs (C_in, N in {32, 64}) with the whole weight tensor LDS-resident.

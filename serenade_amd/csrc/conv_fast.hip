@@ -31,9 +31,6 @@ constexpr int BK = 32;
 // 256 B of zeros: the source of every padded / masked operand row
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
 
-#ifdef SRN_DBG_TIMING
-__device__ unsigned long long g_dbg[1024 * 4 * 4];
-#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -68,14 +65,6 @@ struct FCfg {
 
 // ACT: SRN_ACT_NONE / SRN_ACT_LEAKY compile-time, -1 = run-time p.pro_act (SiLU / Mish).
 // WPL: B operand is the pre-split weight plane image (p.w_hi); otherwise fp32 rows split in the loop (Q K^T).
-// APL (developer builds, -DSRN_DBG_APL): the A operand arrives as bf16 hi|lo planes too, so the loop has no split at
-// all.  Measured on 10240 x 2048 x 2048: 350 vs 341 TFLOP/s (+2.7 %) -- the in-loop split is not what bounds the
-// kernel, so activation producers keep writing plain fp32.
-#ifdef SRN_DBG_APL
-constexpr bool APL = true;
-#else
-constexpr bool APL = false;
-#endif
 
 template <class C, int ACT, bool WPL>
 __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
@@ -225,17 +214,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
       }
       return;
     }
-    if constexpr (APL) {
-      unsigned char* dsta = (c4 < 4 ? sa_hi : sa_lo) + stb_off;
-#pragma unroll
-      for (int i = 0; i < C::A_LD; ++i) {
-        // pass the value through an opaque asm: a pure global -> register -> LDS copy of the whole set is turned
-        // into memcpys of a stack object (scratch) by the optimizer
-        float4 v = R.pa[i];
-        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-        *reinterpret_cast<float4*>(dsta + i * 2048) = v;
-      }
-    } else {
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
       float4 v = R.pa[i];
@@ -255,7 +233,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
       split_pair(v.z, v.w, hi.y, lo.y);
       *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
       *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
-    }
     }
     if constexpr (WPL) {
       unsigned char* dst = (c4 < 4 ? sb_hi : sb_lo) + stb_off;
@@ -326,11 +303,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-#ifdef SRN_DBG_HALFLDS  // timing-only experiment (wrong arithmetic): the second k16 half re-reads nothing from LDS
-      const int choff = (((lh) ^ sw) & 3) << 4;
-#else
       const int choff = (((kk * 2 + lh) ^ sw) & 3) << 4;
-#endif
       bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -342,27 +315,6 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
         bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + fr_b + n * 2048 + choff);
         bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + fr_b + n * 2048 + choff);
       }
-#ifdef SRN_DBG_MFMA16
-      // timing-only experiment (wrong arithmetic): the same FLOPs issued as 16x16x32 MFMAs
-      {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                f32x4 c;
-                const int o = (kk * 2 + h) * 4;
-                c[0] = acc[m][n][o], c[1] = acc[m][n][o + 1], c[2] = acc[m][n][o + 2], c[3] = acc[m][n][o + 3];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t == 0 ? al[m] : ah[m], t == 1 ? bl[n] : bh[n], c, 0, 0, 0);
-                acc[m][n][o] = c[0], acc[m][n][o + 1] = c[1], acc[m][n][o + 2] = c[2], acc[m][n][o + 3] = c[3];
-              }
-        continue;
-      }
-#endif
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -394,8 +346,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     constexpr int N_DSR = (MT + NT) * 4;
     constexpr int N_LD = C::A_LD + C::B_LD;
     constexpr int N_VALU = F32 ? C::A_LD * (ACT == SRN_ACT_NONE ? 0 : 8) + N_LD
-                               : (APL ? 0 : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18)) + (WPL ? 0 : C::B_LD * 10) + N_LD;
-    constexpr int N_DSW = F32 ? C::A_LD + C::B_LD : (APL ? C::A_LD : C::A_LD * 2) + (WPL ? C::B_LD : C::B_LD * 2);
+                               : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10) + N_LD;
+    constexpr int N_DSW = F32 ? C::A_LD + C::B_LD : C::A_LD * 2 + (WPL ? C::B_LD : C::B_LD * 2);
     constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
     __builtin_amdgcn_sched_group_barrier(0x100, F32 ? (MT + NT) : (MT + NT) * 2, 0);  // fragments of the first k slice
 #pragma unroll
@@ -438,43 +390,14 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
   __syncthreads();
   int step = 0;
   // invariant: LDS[0] holds tile `step`; R0 holds the raw tile step+1 (or a parked dummy)
-#ifdef SRN_DBG_TIMING
-  // developer build: per-wave cycle counts of the three loop segments (issue / MFMA+staging / barrier wait)
-  unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tk_start = __builtin_readcyclecounter();
-#define SRN_TICK(acc_)                                          \
-  {                                                             \
-    __builtin_amdgcn_sched_barrier(0);                          \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    acc_ += now_ - tk_start;                                    \
-    tk_start = now_;                                            \
-    __builtin_amdgcn_sched_barrier(0);                          \
-  }
-#else
-#define SRN_TICK(acc_)
-#endif
   for (; step + 2 < n_steps; step += 2) {
     fused(0, 1, R0, R1);
-    SRN_TICK(tq1)
     cursor_advance();
-    SRN_TICK(tq0)
     __syncthreads();
-    SRN_TICK(tq2)
     fused(1, 0, R1, R0);
-    SRN_TICK(tq1)
     cursor_advance();
-    SRN_TICK(tq0)
     __syncthreads();
-    SRN_TICK(tq2)
   }
-#ifdef SRN_DBG_TIMING
-  if (lane == 0 && blockIdx.x < 1024) {
-    unsigned long long* d = g_dbg + (blockIdx.x * 4 + wave) * 4;
-    d[0] = tq0;
-    d[1] = tq1;
-    d[2] = tq2;
-    d[3] = (unsigned long long)(step / 2);
-  }
-#endif
   compute(0);
   if (step + 1 < n_steps) {
     store(1, R0);
@@ -488,12 +411,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
 template <class C, int ACT, bool WPL>
 int launch_fast3(const SrnConvParams& p, hipStream_t stream) {
   constexpr int SMEM = C::SMEM_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fast_kernel<C, ACT, WPL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  static SrnSmemAttr smem_attr;
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_fast_kernel<C, ACT, WPL>), SMEM)) return e;
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
@@ -551,9 +470,3 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
   }
 }
 
-#ifdef SRN_DBG_TIMING
-// developer build only: copy the per-wave segment cycle counts of the last conv_fast launch to the host
-extern "C" int srn_dbg_timing(unsigned long long* host_dst, int n_words) {
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -73,11 +73,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   const int zh = z - zb * p.n_head;
   const int t0 = mt_i * BM;
   const int n0 = nt_i * BN;
-#ifdef SRN_DEBUG_SAMETILE  // timing experiment: every block loads tile (0, 0) -> all operand traffic hits L2
-  const int t0_ld = 0, n0_ld = 0;
-#else
-  const int t0_ld = t0, n0_ld = n0;
-#endif
 
   const float* __restrict__ in0 = p.in0 + (int64_t)zb * p.in0_bs + (int64_t)zh * p.in0_hs;
   const float* __restrict__ in1 = p.in1 ? p.in1 + (int64_t)zb * p.in1_bs : nullptr;
@@ -95,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   int a_tb[C::A_LD];          // input row before the tap offset, or INT_MIN/2 if the output row is invalid
 #pragma unroll
   for (int i = 0; i < C::A_LD; ++i) {
-    const int t = t0_ld + lrow + 32 * i;
+    const int t = t0 + lrow + 32 * i;
     a_tb[i] = (t < p.T_out) ? t * p.in_stride : -(1 << 29);
   }
 
@@ -110,10 +105,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   // Issue-only: every load targets an in-bounds (clamped) address and nothing here consumes a loaded value, so
   // no s_waitcnt is needed until store_step() -- the loads stay in flight under the MFMA phase.
   auto load_step = [&](int step, Regs& R) {
-#ifdef SRN_DBG_NOLOAD
-    R.a_ok = R.b_ok = ~0u;
-    return;
-#endif
     const int tap = step / n_chunks;
     const int chunk = step - tap * n_chunks;
     const int ch = chunk * BK + c4 * 4;
@@ -149,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
       R.b_ok = 0;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
-        int n = n0_ld + lrow + 32 * i;
+        int n = n0 + lrow + 32 * i;
         const bool ok = kok && n < p.N;
         R.b_ok |= (ok ? 1u : 0u) << i;
         n = min(n, p.N - 1);
@@ -176,13 +167,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
   const int pro_act = p.pro_act;
   const float pro_slope = p.pro_slope;
   auto store_step = [&](int stage, Regs& R) {
-#ifdef SRN_DBG_NOSTORE
-#pragma unroll
-    for (int i = 0; i < C::A_LD; ++i) asm volatile("" ::"v"(R.pa[i].x), "v"(R.pa[i].y), "v"(R.pa[i].z), "v"(R.pa[i].w));
-#pragma unroll
-    for (int i = 0; i < C::B_LD; ++i) asm volatile("" ::"v"(R.pb[i].x), "v"(R.pb[i].y), "v"(R.pb[i].z), "v"(R.pb[i].w));
-    return;
-#endif
     if constexpr (PREC == 1) {
       unsigned char* sa_hi = smem_b + stage * BF_STAGE;
       unsigned char* sa_lo = sa_hi + BM * 64;
@@ -302,13 +286,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
           bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + o);
           bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + o);
         }
-#ifdef SRN_DBG_NOMFMA
-#pragma unroll
-        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(bh[n]), "v"(bl[n]));
-        continue;
-#endif
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -441,12 +418,8 @@ const TileInfo kTiles[] = {{1, 128, 128, 64, {1.00f, 1.00f}}, {2, 128, 64, 64, {
 template <class C, int ACT, int PREC>
 int launch_prec(const SrnConvParams& p, hipStream_t stream) {
   constexpr int SMEM = PREC == 1 ? 2 * (C::BM + C::BN) * 128 : C::SMEM_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<C, ACT, PREC>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  static SrnSmemAttr smem_attr;
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_gemm_kernel<C, ACT, PREC>), SMEM)) return e;
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
@@ -545,10 +518,6 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
 
   int tile = p.tile > 0 ? p.tile : pick_tile(p);
   if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
-  if (p.ws != nullptr) {
-    const int r = srn_conv_planes_try(p, tile, stream);
-    if (r != 0) return r < 0 ? r : 0;
-  }
   if (p.no_halo != 1 && p.no_halo != 3) {
     // thin convs (<= 64 channels in and out): persistent strip kernel with LDS-resident weights
     const int r = srn_conv_strip_try(p, stream);

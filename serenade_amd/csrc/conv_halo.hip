@@ -246,12 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const SrnConvParams p
 
 template <class C, int ACT>
 int launch_halo(const SrnConvParams& p, int min_off, int halo, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<C, ACT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM_BYTES));
-    attr_done = true;
-  }
+  static SrnSmemAttr smem_attr;
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_halo_kernel<C, ACT>), C::SMEM_BYTES)) return e;
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;

@@ -170,12 +170,9 @@ extern "C" int srn_conv2d_bn_relu(const float* x, const float* w, const float* b
   hipStream_t st = (hipStream_t)stream;
 #define SRN_C2D(WOM)                                                                                              \
   do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
-      SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_bn_relu_kernel<WOM>),               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-      attr = true;                                                                                                \
-    }                                                                                                             \
+    static SrnSmemAttr smem_attr;                                                                                 \
+    if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv2d_bn_relu_kernel<WOM>), 160 * 1024))   \
+      return e;                                                                                                   \
     hipLaunchKernelGGL(conv2d_bn_relu_kernel<WOM>, grid, dim3(256), smem, st, x, w, bn_scale, bn_shift, y, H, W, Ci, \
                        Co, Ho, Wo);                                                                               \
   } while (0)
@@ -213,12 +210,8 @@ extern "C" int srn_style_token_attention(const float* ref, const float* embs, co
   SRN_CHECK_ARG(B > 0 && F > 0 && n_head > 0 && F % n_head == 0 && n_tok > 0, "style_token_attention: bad sizes");
   const size_t smem = (size_t)(F + n_tok * dk_in + 2 * n_tok * F + n_head * n_tok + F) * sizeof(float);
   SRN_CHECK_ARG(smem <= 160 * 1024, "style_token_attention: too large for LDS");
-  static bool attr = false;
-  if (!attr) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&style_token_attention_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  static SrnSmemAttr smem_attr;
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&style_token_attention_kernel), 160 * 1024)) return e;
   hipLaunchKernelGGL(style_token_attention_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, ref, embs, wq, bq, wk,
                      bk, wv, bv, wo, bo, out, Dq, n_tok, dk_in, F, n_head);
   SRN_CHECK_LAUNCH();

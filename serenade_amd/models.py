@@ -54,6 +54,8 @@ class _Packed(nn.Module):
         self._plans = {}
 
     def _invalidate(self):
+        if self._packed is not None:
+            ops.drop_weight_planes(_tensors_of(self._packed))
         self._packed = None
         self._plans = {}
         for m in self.children():
@@ -81,7 +83,35 @@ class _Packed(nn.Module):
 
 
 def _dev_f32(t, dev):
-    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    """private fp32 device copy: packed weights never alias a live nn.Parameter, so an in-place reload of the
+    parameter (load_state_dict) cannot change -- or be missed by -- anything derived from the packed tensor"""
+    r = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return r.clone() if r.data_ptr() == t.data_ptr() else r
+
+
+def _lru_get(cache, key, capacity, make):
+    """dict used as an LRU (insertion order = recency): a hit moves the entry to the back, a miss evicts only the
+    least recently used entries beyond `capacity` -- never the plan in use (the B = 1 decode loop sees a new length
+    with almost every utterance; GroupNorm runs over the padded length, so lengths cannot be bucketed)."""
+    if key in cache:
+        cache[key] = cache.pop(key)
+    else:
+        cache[key] = make()
+        while len(cache) > capacity:
+            cache.pop(next(iter(cache)))
+    return cache[key]
+
+
+def _tensors_of(obj):
+    """all tensors inside a nested dict / list / tuple"""
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
 
 
 def _fold_wn(sd, name):
@@ -189,11 +219,7 @@ class Decoder(_Packed):
 
     def plan(self, B, L, n_steps, euler, per_sample_t=False):
         key = (B, L, n_steps, bool(euler), bool(per_sample_t), ops.DEFAULT_PRECISION)
-        if key not in self._plans:
-            if len(self._plans) > 8:
-                self._plans.clear()
-            self._plans[key] = DecoderPlan(self, B, L, n_steps, euler, per_sample_t)
-        return self._plans[key]
+        return _lru_get(self._plans, key, 8, lambda: DecoderPlan(self, B, L, n_steps, euler, per_sample_t))
 
     @torch.no_grad()
     def forward(self, x, mask, mu, t, speaker_features):
@@ -431,7 +457,6 @@ class DecoderPlan:
         if self.steps is None or self._dts != dts:
             self.steps = [self._build_step(k, dts[k]) for k in range(self.n)]
             self._dts = dts
-            ops.attach_workspace(self.pre + [op for ol in self.steps for op in ol], self.h0.device)
             self._runner.invalidate()
 
     def set_lens(self, lens):
@@ -601,7 +626,6 @@ class Conv1dResnet(_Packed):
         xin = x.detach().to(torch.float32).contiguous()
         out = torch.empty(B, T, self.out_dim, device=x.device, dtype=torch.float32)
         ol = self.build_ops(xin, B, T, out, T * self.out_dim, self.out_dim)
-        ops.attach_workspace(ol, x.device)
         for op in ol:
             op()
         return out
@@ -709,7 +733,6 @@ class StyleEncoder(_Packed):
         B, T, _ = speech.shape
         out = torch.empty(B, self.gst_token_dim, device=speech.device, dtype=torch.float32)
         ol = self.build_ops(speech.detach().to(torch.float32).contiguous(), B, T, out)
-        ops.attach_workspace(ol, speech.device)
         for op in ol:
             op()
         return out
@@ -814,7 +837,6 @@ class Serenade(_Packed):
         pl.set_lens(total)
         pl._xin.copy_(z)
         pl.load_ops[0]()
-        ops.attach_workspace(ol, dev)
         for op in ol:
             op()
         pl.run()

@@ -16,9 +16,6 @@ from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_LEAKY
 
 
 DEFAULT_PRECISION = _lib.PREC_FP32  # contraction arithmetic of ops built without an explicit precision
-# Opt-in: split-bf16 ops stream pre-split bf16 planes from an HBM workspace through LDS-DMA (conv_planes.hip).
-# Parity-tested, but measured slower than the in-kernel split (8.1 vs 6.7 ms per Euler step), so off by default.
-USE_PLANES = os.environ.get("SERENADE_AMD_PLANES", "0") == "1"
 NO_HALO = False  # True: force the generic kernel everywhere (A/B timing)
 PROFILE = None  # set to a list by bench.py to collect (start, end) HIP events per conv_gemm launch
 
@@ -45,7 +42,7 @@ def _f32(t):
 class ConvOp:
     """A prebuilt srn_conv_gemm call (parameters frozen, pointers borrowed from live tensors)."""
 
-    __slots__ = ("p", "kw", "_fn", "_ws", "_wplanes", "ws_need")
+    __slots__ = ("p", "kw", "_fn", "_wplanes")
 
     def __init__(self, **kw):
         self.kw = kw  # kept for introspection (tests emulate the C-ABI contract from it) and to pin the tensors
@@ -83,33 +80,13 @@ class ConvOp:
         p.no_halo = 1 if NO_HALO else int(no_halo)  # 0 auto, 1 tiled kernels only, 2 force halo, 3 generic kernel only, 4 force strip
         self.p = p
         self._fn = _lib.lib().srn_conv_gemm
-        self._ws = self._wplanes = None
+        self._wplanes = None
         if p.precision == _lib.PREC_BF16X3:
-            # static weights are split once, at plan-build time, into the bf16 hi|lo plane image conv_fast.hip
-            # (and conv_planes.hip) stream straight into LDS
+            # static weights are split once, at plan-build time, into the bf16 hi|lo plane image conv_fast.hip streams
+            # straight into LDS
             if isinstance(w, torch.Tensor) and w.is_cuda and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor:
                 self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw)
                 p.w_hi = self._wplanes[0].data_ptr()
-            if USE_PLANES and not geglu:
-                self._prepare_planes(w, int(n_batch) * int(n_head), bool(w_nmajor))
-
-    # ---- split-bf16 fast path: operands as (hi, lo) bf16 planes in an HBM workspace (conv_planes.hip)
-    def _prepare_planes(self, w, Z, w_nmajor):
-        p = self.p
-        cp = (p.C_in + 31) // 32 * 32
-        static_w = isinstance(w, torch.Tensor) and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor and w.is_cuda
-        w_total = 0
-        if not static_w:
-            if p.n_taps != 1:
-                return  # multi-tap with non-static weights: not supported by the planes path
-            w_total = p.N * p.n_taps * cp * (Z if (p.w_bs or p.w_hs) else 1)
-        self.ws_need = 256 + 4 * Z * p.T_in * cp + 4 * w_total + 64
-
-    def set_workspace(self, ws):
-        """ws: uint8 CUDA tensor (256-B aligned) of at least self.ws_need bytes, shared by the ops of one stream."""
-        if getattr(self, "ws_need", 0) and ws is not None and ws.numel() >= self.ws_need:
-            self._ws = ws
-            self.p.ws, self.p.ws_bytes = ws.data_ptr(), ws.numel()
 
     def __call__(self, stream=None):
         if PROFILE is not None and stream is None:
@@ -123,22 +100,36 @@ class ConvOp:
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
 
 
-_WPLANES = {}  # (data_ptr, shape, taps, C_in) -> (hi, lo) bf16 weight planes, split once at load time
-_WS = {}       # device -> shared uint8 workspace
+_WPLANES = {}  # (data_ptr, version, shape, ...) -> (planes, weight) bf16 weight planes, split once per weight VALUE
 
 
 def clear_caches():
-    """Drop the weight-plane cache and the shared workspaces (long-running services that load many checkpoints).
+    """Drop the weight-plane cache (long-running services that load many checkpoints).
     Ops already built keep their own references, so existing plans stay valid."""
     _WPLANES.clear()
-    _WS.clear()
+
+
+def drop_weight_planes(tensors):
+    """Forget the cached planes of the given weight tensors (a module re-packing its weights calls this, so planes
+    of a previous checkpoint can never be contracted with the new one even when the storage address is reused)."""
+    ptrs = {t.data_ptr() for t in tensors if isinstance(t, torch.Tensor)}
+    for key in [k for k in _WPLANES if k[0] in ptrs]:
+        del _WPLANES[key]
 
 
 def weight_planes(w, N, n_taps, C_in, ldw):
     """fp32 packed weights [N][n_taps * C_in] -> bf16 planes [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32],
-    hi = bf16(w), lo = bf16(w - hi) (round-to-nearest-even, the same split the kernels apply to activations)."""
-    key = (w.data_ptr(), tuple(w.shape), N, n_taps, C_in, ldw)
+    hi = bf16(w), lo = bf16(w - hi) (round-to-nearest-even, the same split the kernels apply to activations).
+    The cache key carries the tensor's in-place version counter: `load_state_dict` copies into the live parameter
+    (same address, version + 1), which therefore misses the cache and is split again."""
+    try:
+        version = w._version
+    except RuntimeError:  # tensors created under torch.inference_mode() carry no counter (and cannot be written)
+        version = -1
+    key = (w.data_ptr(), version, tuple(w.shape), N, n_taps, C_in, ldw)
     if key not in _WPLANES:
+        for stale in [k for k in _WPLANES if k[0] == key[0] and k[2:] == key[2:]]:
+            del _WPLANES[stale]  # an older value of the same tensor
         cp = (C_in + 31) // 32 * 32
         src = w.reshape(-1)[: N * ldw].view(N, ldw)[:, : n_taps * C_in].reshape(N, n_taps, C_in)
         full = torch.zeros(N, n_taps, cp, device=w.device, dtype=torch.float32)
@@ -149,24 +140,6 @@ def weight_planes(w, N, n_taps, C_in, ldw):
         pl = torch.stack([hi.view(N, n_taps, cp // 32, 32), lo.view(N, n_taps, cp // 32, 32)], dim=3).contiguous()
         _WPLANES[key] = (pl, w)  # keep `w` alive so the data_ptr key stays unique
     return _WPLANES[key]
-
-
-def attach_workspace(op_list, device):
-    """Give every split-bf16 ConvOp of `op_list` the shared per-device workspace (grown to the largest need).
-    Ops run back to back on one stream, so one workspace serves them all."""
-    need = 0
-    for op in op_list:
-        if isinstance(op, ConvOp):
-            need = max(need, getattr(op, "ws_need", 0) or 0)
-    if need == 0 or torch.device(device).type != "cuda":
-        return
-    ws = _WS.get(str(device))
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=device)
-        _WS[str(device)] = ws
-    for op in op_list:
-        if isinstance(op, ConvOp):
-            op.set_workspace(ws)
 
 
 class CallOp:

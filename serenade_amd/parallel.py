@@ -9,6 +9,15 @@ import torch
 import torch.distributed as dist
 
 
+def rank_world():
+    """(rank, world size) of this process: the initialised process group's, else torchrun's environment, else
+    (0, 1)."""
+    import os
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
 def shard_range(n_items, rank, world_size):
     """Contiguous split of n_items over world_size ranks: ranks < n_items % world_size get one extra."""
     q, r = divmod(n_items, world_size)

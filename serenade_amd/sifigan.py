@@ -281,7 +281,6 @@ class SiFiGANPlan:
         self.wave = f(B, Rf)
         ol.append(ops.out_conv_tanh_op(cur, P["fn_out_w"], P["fn_out_b"], self.wave, B, Rf, Cl, ks, slope))
         self.ops = ol
-        ops.attach_workspace(ol, dev)
 
     def load(self, x, c, d):
         self._c_in.copy_(c)

@@ -88,9 +88,10 @@ def find_files(root_dir, query="*.h5", include_root_dir=True):
 
 
 def write_wav_pcm16(path, wave, sr):
-    """`soundfile.write(path, wave, sr, "PCM_16")` (ssc_decode.py:361-366,449-455); falls back to the stdlib
-    `wave` module with libsndfile's float -> int16 rule (scale 32767... clip, round-to-nearest) when soundfile is
-    not installed."""
+    """`soundfile.write(path, wave, sr, "PCM_16")` (ssc_decode.py:361-366,449-455).  Without the soundfile package
+    the stdlib `wave` module writes the same samples: libsndfile converts normalised floats to PCM_16 as
+    `lrint(x * 0x7FFF)` (round-half-even, scale 32767); values outside [-1, 1] are clipped here instead of wrapping
+    (the generator ends in tanh, so converted audio never gets there)."""
     x = np.asarray(wave)
     try:
         import soundfile as sf
@@ -100,7 +101,7 @@ def write_wav_pcm16(path, wave, sr):
         pass
     import wave as _wave
     if x.dtype.kind == "f":
-        x = np.clip(np.rint(x.astype(np.float64) * 32768.0), -32768, 32767).astype("<i2")
+        x = np.clip(np.rint(x.astype(np.float64) * 32767.0), -32768, 32767).astype("<i2")
     else:
         x = x.astype("<i2")
     with _wave.open(path, "wb") as f:

@@ -19,7 +19,7 @@ import torch
 import yaml
 
 from . import _shapes, ops
-from .models import _Packed, _dev_f32, _fold_wn, _require_cuda
+from .models import _Packed, _dev_f32, _fold_wn, _lru_get, _require_cuda
 from .ops import ACT_LEAKY, POST_DIV, RES_ADD, ConvOp
 
 __all__ = ["HiFiGANGenerator", "Vocoder", "load_vocoder", "hifigan_state_shapes"]
@@ -122,11 +122,7 @@ class HiFiGANGenerator(_Packed):
 
     def plan(self, B, T):
         key = (B, T, ops.DEFAULT_PRECISION)
-        if key not in self._plans:
-            if len(self._plans) > 4:
-                self._plans.clear()
-            self._plans[key] = HiFiGANPlan(self, B, T)
-        return self._plans[key]
+        return _lru_get(self._plans, key, 4, lambda: HiFiGANPlan(self, B, T))
 
     @torch.no_grad()
     def forward(self, c):
@@ -232,7 +228,6 @@ class HiFiGANPlan:
         self.ops = ol
         self._runner = ops.GraphRunner(lambda: self.ops)
         self._keep = (h, u, p0, p1, xt, acc)
-        ops.attach_workspace(ol, dev)
 
     def run(self):
         self._runner()

@@ -1,6 +1,6 @@
 """GPU fuzz of the one contraction entry point (srn_conv_gemm): seeded random shapes / taps / strides / paddings /
 masks / concat inputs / prologues / epilogues, each run through every kernel the dispatcher can pick (conv_fast,
-conv_strip, conv_halo, the LDS-DMA planes kernel, the generic conv_gemm kernel; both arithmetic modes) and compared with
+conv_strip, conv_halo, the generic conv_gemm kernel; both arithmetic modes) and compared with
 the executable spec of the ABI (tests/_emulator.py) on identical inputs."""
 import numpy as np
 import pytest

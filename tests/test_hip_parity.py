@@ -83,11 +83,10 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     """run the kernel (for each tile id) and the spec on clones of the same inputs; compare every buffer"""
     base = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
     tol = KTOL.k if tol is None else tol
-    # split-bf16 has three kernels behind the one entry point: conv_fast (regular shapes; auto), the LDS-DMA planes
-    # pipeline (workspace attached) and the generic conv_gemm kernel (no_halo=3 forces it)
-    variants = ("auto", "planes", "generic") if serenade_amd.get_precision() == "bf16x3" else ("auto", "generic")
+    # two kernel families behind the one entry point: the specialised ones (conv_fast / halo / strip; auto) and the
+    # generic conv_gemm kernel (no_halo=3 forces it)
+    variants = ("auto", "generic")
     for tile, variant in [(t, u) for t in tiles for u in variants]:
-        use_ws = variant == "planes"
         cpu = {}
         memo = {}
 
@@ -109,15 +108,7 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
             if gpu.get("no_halo"):
                 continue
             gpu["no_halo"] = 3
-        saved, ops.USE_PLANES = ops.USE_PLANES, use_ws
-        try:
-            op = ops.ConvOp(**gpu)
-        finally:
-            ops.USE_PLANES = saved
-        if use_ws:  # split-bf16 through pre-split planes + LDS-DMA pipeline (conv_planes.hip)
-            ops.attach_workspace([op], dev)
-            if not op.p.ws:
-                continue
+        op = ops.ConvOp(**gpu)
         op()
         torch.cuda.synchronize()
         _emulator.emul_conv(cpu)

@@ -289,12 +289,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_planes_kernel(c
 template <class C>
 int launch_planes(const SrnConvParams& p, const PlaneArgs& q, hipStream_t stream) {
   constexpr int SMEM = C::SMEM_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SRN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel<C>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  static SrnSmemAttr smem_attr;
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_planes_kernel<C>), SMEM)) return e;
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
   const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;

@@ -2,7 +2,7 @@
 """Developer tool (GPU only): time one plain GEMM shape over a sweep of K and fit t = a + b*K, which separates the
 per-block fixed cost (prologue + epilogue, a) from the main-loop rate (b).
 
-    python tools/ksweep.py [--planes] [--fp32] [M N]
+    python tools/ksweep.py [--fp32] [M N]
 """
 import os
 import sys
@@ -17,9 +17,7 @@ from serenade_amd import _lib, ops  # noqa: E402
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     M, N = (int(args[0]), int(args[1])) if len(args) >= 2 else (10240, 2048)
-    planes = "--planes" in sys.argv
     prec = _lib.PREC_FP32 if "--fp32" in sys.argv else _lib.PREC_BF16X3
-    ops.USE_PLANES = planes
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     ks = [128, 256, 512, 1024, 2048, 4096]
@@ -31,8 +29,6 @@ def main():
         for tile in (0, 1, 2, 4, 6):
             op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
                             precision=prec, tile=tile)
-            if planes:
-                ops.attach_workspace([op], dev)
             op()
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

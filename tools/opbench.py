@@ -87,10 +87,8 @@ def sweep(oplist, reps=5):
 def main():
     if "--no-halo" in sys.argv:
         ops.NO_HALO = True
-    ops.USE_PLANES = "--planes" in sys.argv
-    if "--bf16x3" in sys.argv:
-        from serenade_amd import _lib
-        ops.DEFAULT_PRECISION = _lib.PREC_BF16X3
+    import serenade_amd
+    serenade_amd.set_precision("fp32" if "--fp32" in sys.argv else "bf16x3")
     dev = torch.device("cuda:0")
     model, voc, sd, gsd = bench.build_models(dev)
     B, T, Tr = (int(os.environ.get(k, d)) for k, d in (("SRN_B", bench.B_PER_GPU), ("SRN_T", bench.T_SRC), ("SRN_TREF", bench.T_REF)))
