@@ -10,10 +10,18 @@ A "step" is one pass of the hot path over one synthetic batch per GPU: `Serenade
 T=1024 source frames with a 256-frame prompt, 10 Euler steps) + `Vocoder.decode_batch`, inputs already resident
 in HBM; with N > 1 every rank converts its own batch (utterances shard embarrassingly, weak scaling) and the
 converted waveforms are gathered on rank 0 over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+
+The top-level `value` / `ms_per_step` / `dtype` / `roofline` are measured in the REFERENCE's precision: exact fp32
+contraction on v_mfma_f32_32x32x2_f32.  The faster split-bf16 product mode (operands as bf16 hi+lo, 3 MFMA per
+product: inside the north-star tolerances but narrower than fp32) is timed in the same run and reported under
+`split_bf16_mode`; the north-star's other sizes under `sweep`; the CPU oracle on the host cores under `cpu_baseline`.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 B_PER_GPU, T_SRC, T_REF, N_EULER = 8, 1024, 256, 10
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak (one MFMA pass; split-bf16 needs three)
+DTYPE = {"fp32": "f32", "bf16x3": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate"}
 
 
 def algorithmic_flops(B, T, T_ref, n):
@@ -35,6 +44,16 @@ def algorithmic_flops(B, T, T_ref, n):
     frame, HiFi-GAN 499e6 per source frame (all of it runs in the conv_gemm kernel; GST's 0.8 GFLOP does not)."""
     L = T + T_ref
     return B * (n * (81.3e6 * L + 24576.0 * L * L) + 11.32e6 * (T + T_ref) + 499e6 * T)
+
+
+def build_id():
+    """hash of the kernel sources + C ABI the loaded library was built from (profiles/ records carry the same id)"""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "serenade_amd", "csrc", "*")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
 
 
 def build_models(dev):
@@ -53,24 +72,112 @@ def build_models(dev):
     return model, voc, sd, gsd
 
 
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def host_cpu():
+    """(model name, physical cores of the machine, CPUs this process may run on)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 CPU quota of the container, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), usable
+
+
 def cpu_baseline(sd, gsd):
-    """The CPU oracle (a port of the reference's CPU path, pinned to its golden vectors) timed on this box's
-    host cores on a bounded sample: ONE utterance of the same workload."""
+    """The CPU oracle (a port of the reference's CPU path, pinned to the reference's golden vectors) timed on this
+    box's host cores, fp32 torch CPU, same synthetic inputs, bounded samples (SURVEY section 8d / BASELINE.md 4):
+      * all usable physical cores: ONE utterance of the headline workload (T=1024, T_ref=256, 10 Euler steps +
+        HiFi-GAN) -- 1 warm-up on a short clip, median of 3;
+      * 1 thread (the recipe's OMP_NUM_THREADS=1, egs/gtsinger/ssc1/path.sh:16): ONE utterance of the C1 shape
+        (T=256, T_ref=256) -- median of 3."""
     from oracle import serenade_oracle as O
     from serenade_amd.utils.synth import HIFIGAN_PARAMS, synth_inputs
-    d = synth_inputs(1, T_SRC, T_ref=T_REF, seed=1235)
-    threads = torch.get_num_threads()
     t1 = torch.ones(80)
     ident = {"mean": 0 * t1, "scale": t1}
-    with torch.no_grad():
-        t0 = time.time()
-        mel = O.serenade_inference(sd, d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
-                                   d["ref_logmel"], d["ref_midi"], d["ref_lft"], d["z"], n_timesteps=N_EULER)
-        O.vocoder_decode(gsd, mel, HIFIGAN_PARAMS, ident, ident)
-        dt = time.time() - t0
-    return {"value": T_SRC / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 utterance of the workload (T={T_SRC}, T_ref={T_REF}, {N_EULER} Euler steps + HiFi-GAN), "
-                      f"fp32 torch CPU, {dt:.1f} s"}
+
+    def run(d):
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            mel = O.serenade_inference(sd, d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
+                                       d["ref_logmel"], d["ref_midi"], d["ref_lft"], d["z"], n_timesteps=N_EULER)
+            O.vocoder_decode(gsd, mel, HIFIGAN_PARAMS, ident, ident)
+            return time.perf_counter() - t0
+
+    model, phys, usable = host_cpu()
+    n_all = max(1, min(phys, usable))
+    saved = torch.get_num_threads()
+    warm = synth_inputs(1, 64, T_ref=32, seed=7)
+    legs = {}
+    try:
+        for name, threads, T in (("all_cores", n_all, 1024), ("one_thread", 1, 256)):
+            torch.set_num_threads(threads)
+            d = synth_inputs(1, T, T_ref=256, seed=1235)
+            run(warm)
+            ts = [run(d) for _ in range(3)]
+            med = statistics.median(ts)
+            legs[name] = {"value": T / med, "unit": "frames/s", "threads": threads, "median_s": med,
+                          "runs_s": [round(t, 3) for t in ts],
+                          "sample": f"1 utterance T={T}, T_ref=256, {N_EULER} Euler steps + HiFi-GAN (8,5,3,2)"}
+    finally:
+        torch.set_num_threads(saved)
+    a = legs["all_cores"]
+    return {"value": a["value"], "unit": "frames/s", "cores": a["threads"], "kind": "port",
+            "sample": a["sample"] + f"; fp32 torch CPU, 1 warm-up, median of 3 ({a['median_s']:.1f} s)",
+            "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "one_thread": legs["one_thread"]}
+
+
+# ---------------------------------------------------------------------------------------------------- traffic record
+def recorded_traffic(precision):
+    """HBM-side bytes per contraction launch from the newest committed PMC record (tools/profile_round.py writes
+    profiles/r*_pmc_traffic.json from two separate rocprofv3 --pmc passes over this command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside a timed run, so the number is
+    read from the record, together with the build it was measured on."""
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not recs:
+        return None
+    try:
+        rec = json.load(open(recs[-1]))
+        m = rec["modes"][precision]
+    except (OSError, ValueError, KeyError):
+        return None
+    return {"bytes_per_launch": m["traffic_bytes_per_launch"], "fetch_bytes_per_launch": m["fetch_bytes_per_launch"],
+            "write_bytes_per_launch": m["write_bytes_per_launch"], "launches": m["launches"],
+            "source": os.path.relpath(recs[-1], ROOT), "measured_on_build": rec.get("build"),
+            "workload": rec.get("workload")}
+
+
+def op_bytes(kw):
+    """operand bytes one contraction launch must move once: A + B read, output written, residuals read"""
+    Z = kw["n_batch"] * kw.get("n_head", 1)
+    taps = len(kw.get("taps", (0,)))
+    n_out = kw.get("N_out", 0) or kw["N"]
+    rd = Z * kw["T_in"] * kw["C_in"] * 4
+    per_z = bool(kw.get("w_bs", 0) or kw.get("w_hs", 0))
+    rd += (Z if per_z else 1) * kw["N"] * taps * kw["C_in"] * 4
+    out_b = Z * kw["T_out"] * n_out * 4
+    rd += out_b * ((kw.get("res") is not None) + (kw.get("res2") is not None))
+    return rd + out_b
 
 
 def main():
@@ -80,7 +187,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--skip-fp32", action="store_true", help="profiling runs: time the headline split-bf16 mode only")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the north-star size sweep (profiling runs)")
+    ap.add_argument("--modes", default="fp32,bf16x3", help="contraction modes to time; the first is the headline "
+                                                           "(profiling runs pass one)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the "
+                    "waveform gather even with one rank (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--graphs", type=int, default=None, help="1/0: replay the plans as hipGraphs (default: library default)")
     # the north-star's other sizes (T in {256, 1024, 4096}, 20 Euler steps); the defaults are the headline workload
     ap.add_argument("--frames", type=int, default=T_SRC, help="source mel frames per utterance")
@@ -89,6 +200,8 @@ def main():
     ap.add_argument("--euler", type=int, default=N_EULER, help="Euler ODE steps")
     args = ap.parse_args()
     B_PER_GPU, T_SRC, T_REF, N_EULER = args.batch, args.frames, args.ref_frames, args.euler
+    modes = [m for m in args.modes.split(",") if m]
+    assert modes and all(m in DTYPE for m in modes), f"--modes takes {sorted(DTYPE)}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -96,34 +209,51 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:  # before any other GPU call of this process
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    import serenade_amd
     from serenade_amd import ops
     from serenade_amd.parallel import gather_waveforms
     from serenade_amd.utils.synth import synth_inputs
 
     model, voc, sd, gsd = build_models(dev)
-    d = synth_inputs(B_PER_GPU, T_SRC, T_ref=T_REF, seed=1235 + rank)
-    g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
+    if args.graphs is not None:
+        ops.set_graphs(bool(args.graphs))
+    gather_ev = []  # (start, end) HIP events around the waveform gather of the timed steps
 
-    def step():
-        mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"],
-                              g["ref_logmel"], g["ref_midi"], g["ref_lft"], n_timesteps=N_EULER, noise=g["z"])
-        wave = voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))  # inference() squeezes B == 1
-        return gather_waveforms(wave, dst=0, uniform=True) if world > 1 else wave
+    def make_step(B, T, T_ref, n, seed):
+        d = synth_inputs(B, T, T_ref=T_ref, seed=seed)
+        g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
+
+        def step(timed=False):
+            mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"],
+                                  g["ref_logmel"], g["ref_midi"], g["ref_lft"], n_timesteps=n, noise=g["z"])
+            wave = voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))  # inference() squeezes B == 1
+            if not use_dist:
+                return wave
+            if timed:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = gather_waveforms(wave, dst=0, uniform=True, always_collective=True)
+                e.record()
+                gather_ev.append((s, e))
+                return out
+            return gather_waveforms(wave, dst=0, uniform=True, always_collective=True)
+
+        return step
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    import serenade_amd
-    if args.graphs is not None:
-        ops.set_graphs(bool(args.graphs))
-
+    step = make_step(B_PER_GPU, T_SRC, T_REF, N_EULER, 1235 + rank)
     fl = algorithmic_flops(B_PER_GPU, T_SRC, T_REF, N_EULER)
 
     def timed(precision):
@@ -134,65 +264,107 @@ def main():
             step()
         sync()
         # HIP events bracket every contraction launch of the FIRST timed step only: an event pair per launch costs
-        # ~3.4 us of drained queue (measured: 87.8 ms/step plain, 92.9 with all 739 launches of every step
-        # bracketed), which would be charged to `value`; one step gives 739 samples of the kernel.
+        # ~3.4 us of drained queue (739 launches: ~2.5 ms), which would otherwise be charged to `value` on every
+        # step; one step gives 739 samples of the kernel.
         prof = []
+        del gather_ev[:]
         t0 = time.perf_counter()
         for i in range(args.steps):
             ops.PROFILE = prof if i == 0 else None
-            step()
+            step(timed=True)
         ops.PROFILE = None
         sync()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
+        elapsed = local_elapsed = time.perf_counter() - t0
+        extra = {}
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        durs = np.array([s.elapsed_time(e) for s, e in prof], dtype=np.float64)  # ms
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            elapsed = max(float(x.item()) for x in every)
+            g_ms = [s.elapsed_time(e) for s, e in gather_ev]
+            extra = {"per_rank_ms_per_step": [float(x.item()) / args.steps * 1e3 for x in every],
+                     "rank0_gather_ms_per_step": sum(g_ms) / max(len(g_ms), 1),
+                     "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                     "gather_bytes_per_rank": B_PER_GPU * T_SRC * 240 * 4}
+        durs = np.array([s.elapsed_time(e) for s, e, _ in prof], dtype=np.float64)  # ms
         n_launch = float(len(durs))  # launches of one step
         gemm_ms = durs.sum()
+        alg_bytes = float(sum(op_bytes(op.kw) for _, _, op in prof))
         achieved = fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+        tr = recorded_traffic(precision)
+        same_workload = (B_PER_GPU, T_SRC, T_REF, N_EULER) == (8, 1024, 256, 10)
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None, "kernel": f"srn_conv_gemm<{precision}> implicit-GEMM contraction kernels "
-                          f"({'conv_fast / conv_halo / conv_gemm' if precision == 'bf16x3' else 'conv_gemm'}, all tiles)",
+                "traffic": tr["bytes_per_launch"] if (tr and same_workload) else None,
+                "kernel": f"srn_conv_gemm<{precision}> implicit-GEMM contraction kernels (conv_fast / conv_halo / "
+                          f"conv_strip / conv_gemm, all tiles)",
                 "launches_per_step": n_launch, "avg_launch_us": (durs.mean() * 1e3) if len(durs) else 0.0,
                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
-                "kernel_time_share": gemm_ms / (elapsed / args.steps * 1e3), "event_sampled_steps": 1}
+                "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
+                "kernel_time_share": gemm_ms / (local_elapsed / args.steps * 1e3), "event_sampled_steps": 1}
+        if tr and same_workload:
+            roof["traffic_record"] = {k: tr[k] for k in ("source", "measured_on_build", "fetch_bytes_per_launch",
+                                                         "write_bytes_per_launch", "launches")}
+            roof["traffic_record"]["current_build"] = build_id()
+            roof["traffic_unit"] = "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         if precision == "bf16x3":
             roof["mfma_per_product"] = 3
             roof["frac_of_split_peak"] = achieved / (peak / 3.0)
-            headline = (B_PER_GPU, T_SRC, T_REF, N_EULER) == (8, 1024, 256, 10)
-            if headline:
-                # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-                # workload (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); recorded, not live:
-                # counters cannot be collected inside a timed run.  profiles/r1_e_pmc_traffic.txt
-                roof["traffic"] = 193.49e6
-                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_e_pmc_traffic.txt)"
-                roof["algorithmic_bytes_per_launch"] = 133.67e6
-        return world * B_PER_GPU * T_SRC * args.steps / elapsed, elapsed, roof
+        value = world * B_PER_GPU * T_SRC * args.steps / elapsed
+        return {"value": value, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "dtype": DTYPE[precision], "x_realtime": value / 100.0, "roofline": roof, **extra}
 
-    # headline: split-bf16 contraction (3 bf16 MFMA per fp32 product, fp32 accumulate); parity gates identical
-    value, elapsed, roof = timed("bf16x3")
-    v32, e32, roof32 = (0.0, 0.0, None) if args.skip_fp32 else timed("fp32")
+    results = {m: timed(m) for m in modes}
+    head = results[modes[0]]
+
+    def sweep():
+        """the north-star's sizes on this GPU: frames/s (source frames only; the UNet also carries the 256-frame
+        prompt), 1 warm-up + 2 timed steps each, no per-launch events"""
+        rows = []
+        for T in (256, 1024, 4096):
+            for n in (10, 20):
+                for B in (1, 8):
+                    st = make_step(B, T, 256, n, 1235)
+                    row = {"B": B, "T": T, "T_ref": 256, "euler_steps": n}
+                    for m in modes:
+                        serenade_amd.set_precision(m)
+                        st()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(2):
+                            st()
+                        torch.cuda.synchronize()
+                        dt = (time.perf_counter() - t0) / 2
+                        row[m] = {"frames_per_s": B * T / dt, "ms_per_batch": dt * 1e3,
+                                  "tflops": algorithmic_flops(B, T, 256, n) / dt / 1e12}
+                    rows.append(row)
+        return rows
+
     out = {
         "metric": f"mel frames/sec converted (UNet ODE + vocoder), 80x{T_SRC}",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate",
-        "data": "synthetic",
+        "value": head["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"B={B_PER_GPU}/GPU x T={T_SRC} source frames (80-dim mel), T_ref={T_REF} prompt, "
                                f"{N_EULER} Euler steps, UNet ODE + HiFi-GAN (8,5,3,2) on GPU; waveform gather to "
-                               f"rank 0 when N>1", "global_batch": world * B_PER_GPU, "x_realtime": value / 100.0},
-        "roofline": roof,
-        "exact_fp32_mode": {"value": v32, "unit": "frames/s", "ms_per_step": e32 / args.steps * 1e3, "dtype": "f32",
-                            "roofline": roof32},
+                               f"rank 0 when N>1", "global_batch": world * B_PER_GPU,
+                   "x_realtime": head["x_realtime"], "precision_vs_reference": "same (fp32)" if modes[0] == "fp32"
+                   else "narrower than the reference's fp32 (split-bf16 operands)", "build": build_id()},
+        "roofline": head["roofline"],
     }
+    for k in ("per_rank_ms_per_step", "rank0_gather_ms_per_step", "world_size_seen", "backend",
+              "gather_bytes_per_rank"):
+        if k in head:
+            out.setdefault("multi_gpu", {})[k] = head[k]
+    for m in modes[1:]:
+        out["split_bf16_mode" if m == "bf16x3" else "exact_fp32_mode"] = results[m]
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["sweep"] = sweep()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, gsd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -171,8 +171,8 @@ template <int CIN, int NT, int ACT>
 int launch_strip(const SrnConvParams& p, int min_off, int halo, hipStream_t stream) {
   const int smem = p.n_taps * (CIN / 32) * 2 * (NT * 32) * 64 + (CIN / 32) * 2 * HR_MAX * 64;
   static SrnSmemAttr smem_attr;  // granted once per device at the most this kernel ever asks for
-  SRN_CHECK_ARG(smem <= 156 * 1024, "conv_strip: %d B of LDS", smem);
-  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_strip_kernel<CIN, NT, ACT>), 156 * 1024)) return e;
+  SRN_CHECK_ARG(smem <= 160 * 1024, "conv_strip: %d B of LDS", smem);
+  if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_strip_kernel<CIN, NT, ACT>), 160 * 1024)) return e;
   const int tiles_per_z = (p.T_out + BM - 1) / BM;
   const int64_t n_tiles = (int64_t)p.n_batch * tiles_per_z;
   SRN_CHECK_ARG(n_tiles > 0 && n_tiles < (1ll << 31), "conv_strip: bad tile count %lld", (long long)n_tiles);

@@ -3,6 +3,7 @@
 // row softmax, and small layout / elementwise helpers.  All tensors are channels-last fp32; every kernel
 // moves 16 B per lane (float4) along the contiguous channel axis and reduces with wavefront shuffles.
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -320,36 +321,47 @@ __global__ void renorm_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
-// HiFi-GAN output stage, one lane per output sample.  x (B, T, C), w (k, C).
+// HiFi-GAN output stage: LeakyReLU -> Conv1d(C -> 1, k) -> tanh.  x (B, T, C) channels-last, w (k, C), y (B, T).
+// HBM-bound (one read of x): a workgroup stages the OC_BT + K - 1 rows its 256 outputs need in LDS with coalesced
+// 16-B loads (LeakyReLU applied on the way in; 144-B row pitch, so the per-lane ds_read_b128 of 16 consecutive rows
+// is conflict-free) and every lane then forms one output from LDS.  The round-1 kernel read its 7 x 128 B per lane
+// straight from global memory, 64 different lines per load instruction (1.2 TB/s).
+constexpr int OC_BT = 256;
 template <int K, int CC>
 __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                             int T, float slope) {
-  __shared__ float sw[K * CC];
-  for (int i = threadIdx.x; i < K * CC; i += 256) sw[i] = w[i];
-  __syncthreads();
+  constexpr int PITCH = CC + 4;  // floats
+  constexpr int ROWS = OC_BT + K - 1;
+  __shared__ __attribute__((aligned(16))) float sx[ROWS * PITCH];
+  __shared__ __attribute__((aligned(16))) float sw[K * CC];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T) return;
+  const int t0 = blockIdx.x * OC_BT;
   const float* xb = x + (int64_t)b * T * CC;
+  for (int i = threadIdx.x; i < K * CC; i += 256) sw[i] = w[i];
+  constexpr int C4 = CC / 4;
+  for (int i = threadIdx.x; i < ROWS * C4; i += 256) {
+    const int r = i / C4, c4 = i - r * C4;
+    const int ti = t0 + r - (K - 1) / 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ti >= 0 && ti < T) v = leaky4(*reinterpret_cast<const float4*>(xb + (int64_t)ti * CC + c4 * 4), slope);
+    *reinterpret_cast<float4*>(sx + r * PITCH + c4 * 4) = v;
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t >= T) return;
   float acc = bias[0];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const int ti = t + j - (K - 1) / 2;
-    if (ti < 0 || ti >= T) continue;
-    const float4* row = reinterpret_cast<const float4*>(xb + (int64_t)ti * CC);
+    const float* row = sx + (threadIdx.x + j) * PITCH;
 #pragma unroll
-    for (int c4 = 0; c4 < CC / 4; ++c4) {
-      float4 v = row[c4];
-      v.x = v.x > 0.f ? v.x : v.x * slope;
-      v.y = v.y > 0.f ? v.y : v.y * slope;
-      v.z = v.z > 0.f ? v.z : v.z * slope;
-      v.w = v.w > 0.f ? v.w : v.w * slope;
-      const float* ww = sw + j * CC + c4 * 4;
-      acc = fmaf(v.x, ww[0], acc);
-      acc = fmaf(v.y, ww[1], acc);
-      acc = fmaf(v.z, ww[2], acc);
-      acc = fmaf(v.w, ww[3], acc);
+    for (int c4 = 0; c4 < C4; ++c4) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
+      const float4 ww = *reinterpret_cast<const float4*>(sw + j * CC + c4 * 4);
+      acc = fmaf(v.x, ww.x, acc);
+      acc = fmaf(v.y, ww.y, acc);
+      acc = fmaf(v.z, ww.z, acc);
+      acc = fmaf(v.w, ww.w, acc);
     }
   }
   y[(int64_t)b * T + t] = tanhf(acc);

@@ -238,6 +238,21 @@ class Decoder(_Packed):
         return pl.read_out()
 
 
+S_BUDGET = 112 << 20  # bytes of attention scores in flight (one chunk); see DecoderPlan
+
+
+def attention_chunks(B, H, pair_bytes, budget_bytes):
+    """[(b0, n_batch, h0, n_head)] covering all (batch, head) pairs in order, each chunk's scores within the budget
+    (a single pair is always admitted): runs of whole batch items when one item's H pairs fit, else runs of heads
+    inside one batch item."""
+    fit = max(1, budget_bytes // max(pair_bytes, 1))
+    if fit >= H:
+        n = -(-B // (fit // H))  # number of chunks, then even them out
+        step = -(-B // n)
+        return [(b0, min(step, B - b0), 0, H) for b0 in range(0, B, step)]
+    return [(b, 1, h0, min(fit, H - h0)) for b in range(B) for h0 in range(0, H, fit)]
+
+
 class DecoderPlan:
     """Preallocated buffers + the op list of `n_steps` estimator calls for one (B, L).
 
@@ -281,8 +296,13 @@ class DecoderPlan:
         bufC, bufA, bufR = f(B, L, Cmax), f(B, L, Cmax), f(B, L, Cmax)
         bufN = f(B, L, Cmax)
         qkv = f(B, L, 3 * inner)
+        # Attention scores are produced and consumed in CHUNKS of (batch, head) pairs through one bounded buffer:
+        # [Q K^T -> softmax -> P V] per chunk, so S is never materialised whole -- the footprint is S_BUDGET instead of
+        # B * H * L^2 * 4 B (50 GiB at B=32 x T=4096 before) -- and a chunk stays inside the 256 MiB Infinity Cache
+        # between its three kernels.  A chunk is a run of whole batch items, or a run of heads of one batch item.
         Lp = _rup(L, 32)
-        S = f(B * H, L, Lp)
+        per_pair = L * Lp * 4
+        S = torch.empty(max(1, min(B * H, S_BUDGET // per_pair)) * L * Lp, device=dev, dtype=torch.float32)
         # V^T per resolution, (B, inner, rup(T, 32)): P.V then contracts k-major rows like every other GEMM.  The pad
         # columns are never written (zeros from allocation) and meet exact zeros of the softmax.
         Vt = {T: f(B, inner, _rup(T, 32)) for T in sorted(set(Ts))}
@@ -351,16 +371,18 @@ class DecoderPlan:
             # q | k row-major into qkv; the v third goes straight to V^T (transposed tail of the epilogue)
             ol.append(conv(bufN, C, T, t["qkv_w"], None, qkv, 3 * inner, T, [0], out_tr=Vt[T], out_tr_col0=2 * inner,
                            out_tr_bs=inner * Tp, ld_out_tr=Tp))
-            # S = Q K^T / sqrt(d)   (batched over B x heads)
-            ol.append(ConvOp(in0=qkv, w=(qkv, inner), out=S, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=hd, N=T,
-                             in0_bs=T * 3 * inner, in0_hs=hd, ld_in0=3 * inner, w_bs=T * 3 * inner, w_hs=hd,
-                             ldw=3 * inner, out_bs=H * T * Tp, out_hs=T * Tp, ld_out=Tp,
-                             alpha=1.0 / math.sqrt(hd)))
-            ol.append(ops.softmax_rows_op(S, ln, B * H, H, T, Tp))
-            # O = P V
-            ol.append(ConvOp(in0=S, w=Vt[T], out=bufO, n_batch=B, n_head=H, T_in=T, T_out=T, C_in=Tp, N=hd,
-                             in0_bs=H * T * Tp, in0_hs=T * Tp, ld_in0=Tp, w_bs=inner * Tp, w_hs=hd * Tp, ldw=Tp,
-                             out_bs=T * inner, out_hs=hd, ld_out=inner))
+            # S = Q K^T / sqrt(d) -> softmax over keys < len -> O = P V, chunk by chunk (see S above)
+            for b0, nb, h0, nh in attention_chunks(B, H, T * Tp * 4, S.numel() * 4):
+                q_off = b0 * T * 3 * inner + h0 * hd
+                ol.append(ConvOp(in0=(qkv, q_off), w=(qkv, q_off + inner), out=S, n_batch=nb, n_head=nh, T_in=T,
+                                 T_out=T, C_in=hd, N=T, in0_bs=T * 3 * inner, in0_hs=hd, ld_in0=3 * inner,
+                                 w_bs=T * 3 * inner, w_hs=hd, ldw=3 * inner, out_bs=nh * T * Tp, out_hs=T * Tp,
+                                 ld_out=Tp, alpha=1.0 / math.sqrt(hd)))
+                ol.append(ops.softmax_rows_op(S, (ln, b0), nb * nh, nh, T, Tp))
+                ol.append(ConvOp(in0=S, w=(Vt[T], b0 * inner * Tp + h0 * hd * Tp), out=(bufO, b0 * T * inner + h0 * hd),
+                                 n_batch=nb, n_head=nh, T_in=T, T_out=T, C_in=Tp, N=hd, in0_bs=nh * T * Tp,
+                                 in0_hs=T * Tp, ld_in0=Tp, w_bs=inner * Tp, w_hs=hd * Tp, ldw=Tp, out_bs=T * inner,
+                                 out_hs=hd, ld_out=inner))
             ol.append(conv(bufO, inner, T, t["o_w"], t["o_b"], X, C, T, [0], res=X, res_mode=RES_ADD, res_bs=T * C,
                            ld_res=C))
             ol.append(ops.layernorm_op(X, t["ln3_w"], t["ln3_b"], bufN, B * T, C))

@@ -17,7 +17,7 @@ from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_LEAKY
 
 DEFAULT_PRECISION = _lib.PREC_FP32  # contraction arithmetic of ops built without an explicit precision
 NO_HALO = False  # True: force the generic kernel everywhere (A/B timing)
-PROFILE = None  # set to a list by bench.py to collect (start, end) HIP events per conv_gemm launch
+PROFILE = None  # set to a list by bench.py to collect (start event, end event, op) per conv_gemm launch
 
 
 def _stream():
@@ -95,7 +95,7 @@ class ConvOp:
             s.record()
             check(self._fn(ctypes.byref(self.p), _stream()), "srn_conv_gemm")
             e.record()
-            PROFILE.append((s, e))
+            PROFILE.append((s, e, self))
             return
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
 

@@ -25,7 +25,7 @@ def shard_range(n_items, rank, world_size):
     return start, start + q + (1 if rank < r else 0)
 
 
-def gather_waveforms(wave, n_samples=None, dst=0, group=None, uniform=False):
+def gather_waveforms(wave, n_samples=None, dst=0, group=None, uniform=False, always_collective=False):
     """Gather per-rank waveform batches on rank `dst`.
 
     wave: (B_local, N_local) float tensor (padded); n_samples: (B_local,) int64 valid lengths or None.
@@ -34,7 +34,8 @@ def gather_waveforms(wave, n_samples=None, dst=0, group=None, uniform=False):
     uniform=True: the caller guarantees the same (B, N) and full lengths on every rank (fixed-shape serving, the
     benchmark): ONE collective, no shape exchange and no host synchronisation, so the host keeps running ahead of
     the GPU into the next batch."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if single and not (always_collective and dist.is_available() and dist.is_initialized()):
         ns = n_samples if n_samples is not None else torch.full((wave.shape[0],), wave.shape[1], dtype=torch.int64)
         return [wave], [ns.cpu()]
     world = dist.get_world_size(group)

@@ -183,6 +183,7 @@ def emul_call(name, a):
     elif name == "srn_softmax_rows":
         s, lens, Z, nh, L, ld = a
         sv = _v(s, Z * L * ld).reshape(Z, L, ld)
+        lens = None if lens is None else _v(lens)
         for z in range(Z):
             ln = L if lens is None else min(int(lens[z // nh]), L)
             row = sv[z, :, :L].clone()

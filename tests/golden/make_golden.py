@@ -192,6 +192,41 @@ def forward_case():
         prior_loss=ret["prior_loss"], cfm_loss=ret["cfm_loss"])
 
 
+def euler20_case():
+    """a3 with the step count of BASELINE configs[2] (20 Euler steps), odd padded length: the reference's own
+    CFM.solve_euler (flow_matching.py:65-93) on explicit noise, plus the states after steps 1, 10 and 20 from a
+    replica of its loop (asserted equal to its result).
+
+        PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py euler20
+    """
+    model = Serenade(**SERENADE_PARAMS).eval()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    est, cfm = model.cfm_decoder.estimator, model.cfm_decoder
+    rng = np.random.default_rng(779)
+    L, lens, n = 57, [57, 40], 20
+    mask = make_non_pad_mask(lens).unsqueeze(1)
+    mu, spk = rnd(rng, 2, 162, L), rnd(rng, 2, 256)
+    z = rnd(rng, 2, 80, L) * 0.667
+    t_span = torch.linspace(0, 1, n + 1)
+    tt, dt = t_span[0], t_span[1] - t_span[0]
+    keep, cur = {}, z
+    for step in range(1, len(t_span)):
+        cur = cur + dt * est(cur, mask, mu, tt, spk)
+        tt = tt + dt
+        if step in (1, 10, 20):
+            keep[step] = cur
+        if step < len(t_span) - 1:
+            dt = t_span[step + 1] - tt
+    final = cfm.solve_euler(z, t_span=t_span, mu=mu, mask=mask, trg_spks=spk)
+    assert torch.equal(final, keep[20])
+    npz("euler20_L57", lens=np.array(lens), mu=mu, spk=spk, z=z, x1=keep[1], x10=keep[10], out=final)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "euler20":
+    euler20_case()
+    sys.exit(0)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "forward":
     forward_case()
     sys.exit(0)

@@ -56,7 +56,10 @@ def _feats(rng, T):
                 f0=np.where(rng.uniform(size=T) > 0.2, rng.uniform(150, 400, T), 0.0))
 
 
-def test_decode_cli_end_to_end(tmp_path):
+def _cli_case(tmp_path, on_gpu):
+    """Build a tiny dump / checkpoint / vocoder / stats tree, run the CLI on it (through the C-ABI emulator on the
+    CPU, or the real library on the GPU) and check files, formats and values against the oracle."""
+    import contextlib
     from joblib import dump
     from sklearn.preprocessing import MinMaxScaler, StandardScaler
     rng = np.random.default_rng(0)
@@ -87,7 +90,7 @@ def test_decode_cli_end_to_end(tmp_path):
                    open(exp / "config.yml", "w"))
     json.dump({"Breathy": str(tmp_path / "ref" / "breathy.npz")}, open(tmp_path / "refs.json", "w"))
 
-    with _emulator.installed():
+    with (contextlib.nullcontext() if on_gpu else _emulator.installed()):
         torch.manual_seed(123)
         ssc_decode.main(["--dumpdir", str(dumpdir), "--stats", str(tmp_path / "stats.joblib"), "--ref-dict",
                          str(tmp_path / "refs.json"), "--outdir", str(outdir), "--checkpoint",
@@ -118,6 +121,17 @@ def test_decode_cli_end_to_end(tmp_path):
     wav = O.vocoder_decode(fold_weight_norm(gsd), mel, GEN_PARAMS, {k: t(v) for k, v in vstats.items()}, trg)
     ref_pcm = np.rint(wav.double().numpy() * 32767.0).astype(np.int16)  # libsndfile: lrint(x * 0x7FFF)
     assert np.abs(pcm.astype(np.int32) - ref_pcm.astype(np.int32)).max() <= 1
+
+
+def test_decode_cli_end_to_end(tmp_path):
+    _cli_case(tmp_path, on_gpu=False)
+
+
+@pytest.mark.gpu
+def test_decode_cli_end_to_end_gpu(tmp_path):
+    """the same case through libserenade_hip.so on cuda:0 (B = 1 loop, files, PCM_16, lf0) vs the CPU oracle"""
+    assert torch.cuda.is_available()
+    _cli_case(tmp_path, on_gpu=True)
 
 
 def test_cli_rejects_bad_argument_combinations(tmp_path):

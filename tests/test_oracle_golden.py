@@ -101,6 +101,18 @@ def test_euler_trace(golden):
     close(out, g["out"], 2e-4)
 
 
+def test_euler_20_steps_odd_padded(golden):
+    """BASELINE configs[2] step count: 20 Euler steps, L = 57 (odd) with a padded row, vs the reference's solve_euler"""
+    g = golden("euler20_L57")
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    mask = O.make_non_pad_mask(g["lens"].tolist()).unsqueeze(1)
+    trace = []
+    out = O.solve_euler(w, T(g["z"]), T(g["mu"]), mask, T(g["spk"]), 20, trace=trace)
+    close(trace[0], g["x1"], 2e-4)
+    close(trace[9], g["x10"], 2e-4)
+    close(out, g["out"], 2e-4)
+
+
 def test_t_schedule_is_fp32_accumulated():
     ts, dts = O.t_schedule(10)
     t_span = torch.linspace(0, 1, 11)

@@ -42,6 +42,23 @@ def test_decoder_forward(model, golden, tag):
     assert nerr(out, g["out"]) < 5e-5
 
 
+@pytest.mark.parametrize("pairs", [1, 3, 4])
+def test_attention_chunking_is_invisible(model, golden, monkeypatch, pairs):
+    """the score buffer holds `pairs` (batch, head) pairs: head-runs inside an item (1, 3) and item-runs (4 = one
+    item's 4 heads) must give the decoder output of the unchunked plan (padded batch of 2, odd L)"""
+    g = golden("decoder_L65")
+    L = 65
+    monkeypatch.setattr(models, "S_BUDGET", pairs * L * 96 * 4)  # rup(65, 32) = 96
+    est = model.cfm_decoder.estimator
+    est._plans.clear()
+    assert len(models.attention_chunks(2, 4, L * 96 * 4, pairs * L * 96 * 4)) == {1: 8, 3: 4, 4: 2}[pairs]
+    mask = O.make_non_pad_mask(g["lens"].tolist()).unsqueeze(1)
+    with _emulator.installed():
+        out = est(T(g["x"]), mask, T(g["mu"]), T(g["t"]), T(g["spk"]))
+    est._plans.clear()
+    assert nerr(out, g["out"]) < 5e-5
+
+
 def test_solve_euler(model, golden):
     g = golden("euler_L48")
     mask = O.make_non_pad_mask(g["lens"].tolist()).unsqueeze(1)
