@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SRN_ABI_VERSION 1
+#define SRN_ABI_VERSION 2
 #define SRN_MAX_TAPS 16
 
 /* prologue activation applied to the gathered input elements */
@@ -102,7 +102,10 @@ typedef struct SrnConvParams {
   int32_t no_halo;    /* kernel selection behind this entry point (testing / A-B timing): 0 = automatic, 1 = tiled kernels
                        * only (no halo, no strip), 2 = halo kernel whenever eligible, 3 = generic conv_gemm kernel only,
                        * 4 = strip kernel whenever eligible */
-  /* ws / ws_bytes / w_lo: reserved, must be NULL / 0 (kept so that the struct layout of ABI version 1 is unchanged).
+  /* ws / ws_bytes: optional caller-owned workspace (16-byte aligned, at least srn_conv_gemm_workspace_bytes(p)
+   * bytes, shared by all calls of one stream).  With it, launches whose tile grid cannot fill the chip are split
+   * over K (conv_splitk.hip); without it (NULL) they run unsplit.  Results agree to fp32 summation order.
+   * w_lo: reserved, NULL.
    * w_hi (SRN_PREC_BF16X3 only): the static weights already split at load time, bf16
    * [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32]; NULL: the kernel splits the fp32 rows of `w` per call. */
   void* ws; int64_t ws_bytes;
@@ -120,6 +123,8 @@ const char* srn_last_error(void);
 
 /* the workhorse above */
 int srn_conv_gemm(const SrnConvParams* p, void* stream);
+/* bytes of workspace the split-K path would use for this call (0: the call is never split) */
+int64_t srn_conv_gemm_workspace_bytes(const SrnConvParams* p);
 
 /*
  * GroupNorm(8 groups, eps) -> Mish -> (+ time_bias[c]) -> * mask   (Block1D tail + the time-embedding add of
@@ -170,6 +175,32 @@ int srn_renorm(const float* x, const float* trg_scale, const float* trg_mean, co
  * x (B, T, C) channels-last, w (k, C), y (B, T). */
 int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int k,
                       float slope, void* stream);
+
+/*
+ * One residual unit of HiFiGANResidualBlock with use_additional_convs (residual_block.py:243-258, loop body):
+ *     xt = Conv1d_k,dil(LeakyReLU(x));  xt = Conv1d_k,1(LeakyReLU(xt));  y = xt + x
+ * fused into ONE launch for thin stages (C = 32 or 64): the receptive-field rows of x are staged once in LDS, the
+ * intermediate `xt` never leaves LDS, weights stream through a double-buffered LDS stage -- one HBM read and one
+ * write per unit instead of five passes.  Optionally the stage bookkeeping of HiFiGANGenerator.forward
+ * (hifigan.py:183-186) rides in the epilogue:  y = (y + res2) / post_div.
+ *   x, out, res2: (n_batch, T, C) channels-last fp32, rows contiguous (ld = C); out must not alias x.
+ *   w1, w2: packed [C][k * C] fp32 (tap-major, as srn_conv_gemm's k-major weights); b1, b2: (C).
+ *   w1_hi, w2_hi: SRN_PREC_BF16X3 only -- the same weights as bf16 planes [C][k][C / 32][hi 32 | lo 32].
+ */
+typedef struct SrnResUnitParams {
+  int32_t n_batch, T, C;
+  int32_t k, dilation;      /* conv1: kernel k, dilation `dilation`; conv2: kernel k, dilation 1; both "same" padded */
+  float slope;              /* LeakyReLU negative slope in front of both convs */
+  const float* x; int64_t x_bs;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  const void* w1_hi; const void* w2_hi;
+  const float* res2; int64_t res2_bs;  /* or NULL */
+  float post_div;           /* 0 or 1: none */
+  float* out; int64_t out_bs;
+  int32_t precision;        /* SRN_PREC_* */
+} SrnResUnitParams;
+
+int srn_hifigan_resunit(const SrnResUnitParams* p, void* stream);
 
 /* SiFiGAN pitch-dependent dilated-conv operand gather (row a9; un-vendored `sifigan` package, parity unpinned):
  * out (B, T, 3C) = [lrelu(x[t]) | lrelu(x[t - r]) | lrelu(x[t + r])], r = rint(d[b, t] * dilation), zero outside. */

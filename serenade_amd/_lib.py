@@ -38,11 +38,23 @@ class SrnConvParams(ctypes.Structure):
     ]
 
 
+class SrnResUnitParams(ctypes.Structure):
+    _fields_ = [
+        ("n_batch", c_int32), ("T", c_int32), ("C", c_int32), ("k", c_int32), ("dilation", c_int32),
+        ("slope", c_float), ("x", c_void_p), ("x_bs", c_int64),
+        ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+        ("w1_hi", c_void_p), ("w2_hi", c_void_p), ("res2", c_void_p), ("res2_bs", c_int64),
+        ("post_div", c_float), ("out", c_void_p), ("out_bs", c_int64), ("precision", c_int32),
+    ]
+
+
 _P = c_void_p
 _SIGS = {
     "srn_abi_version": (c_int, []),
     "srn_last_error": (c_char_p, []),
     "srn_conv_gemm": (c_int, [POINTER(SrnConvParams), _P]),
+    "srn_conv_gemm_workspace_bytes": (c_int64, [POINTER(SrnConvParams)]),
+    "srn_hifigan_resunit": (c_int, [POINTER(SrnResUnitParams), _P]),
     "srn_gn_mish_apply": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "srn_resblock_tail": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int,
                                   c_float, c_float, _P]),
@@ -77,7 +89,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.srn_abi_version() != 1:
+        if h.srn_abi_version() != 2:
             raise RuntimeError("libserenade_hip.so ABI version mismatch")
         _lib = h
     return _lib

@@ -229,10 +229,37 @@ __device__ __forceinline__ void conv_epilogue(const SrnConvParams& p, f32x16 (&a
     conv_epilogue_impl<MT, NT, false, true>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
 }
 
+// split-K: raw partial sums of one wave's accumulator tiles to the workspace slab [slice][z][T_out][N]
+template <int MT, int NT>
+__device__ __forceinline__ void splitk_store(const SrnConvParams& p, f32x16 (&acc)[MT][NT], const int slice,
+                                             const int z, const int t0, const int n0, const int wm0, const int wn0,
+                                             const int lane) {
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int64_t Z = (int64_t)p.n_batch * p.n_head;
+  float* ws = reinterpret_cast<float*>(p.ws) + (((int64_t)slice * Z + z) * p.T_out) * p.N;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = n0 + wn0 + n * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = t0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.T_out && col < p.N) ws[(int64_t)row * p.N + col] = acc[m][n][r];
+      }
+    }
+}
+
 // implemented in conv_halo.hip: receptive-field ("halo") variant for stride-1 multi-tap convs in split-bf16.
 // Returns 1 if it handled the launch, 0 if the shape is not eligible, < 0 on error.
 int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);
 // implemented in conv_fast.hip: lean split-bf16 kernel for C_in % 32 == 0, k-major weights.  Same return codes.
-int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream);
+int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit = 1);
+// implemented in conv_splitk.hip: K slices for launches that cannot fill the chip (1 = do not split), the workspace
+// they need, and the reduction + epilogue over the partial sums.
+int srn_splitk_plan(const SrnConvParams& p);
+int64_t srn_splitk_bytes(const SrnConvParams& p, int ksplit);
+int srn_splitk_reduce(const SrnConvParams& p, int ksplit, hipStream_t stream);
 // implemented in conv_strip.hip: thin convs (C_in, N in {32, 64}) with the whole weight tensor LDS-resident.
 int srn_conv_strip_try(const SrnConvParams& p, hipStream_t stream);

@@ -68,14 +68,19 @@ struct FCfg {
 
 template <class C, int ACT, bool WPL>
 __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const SrnConvParams p, const int m_tiles,
-                                                           const int n_tiles) {
+                                                           const int n_tiles, const int ksplit) {
   constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int logical = xcd_logical_block();
+  int logical = xcd_logical_block();
+  // split-K (ksplit > 1): the grid holds ksplit copies of the tile set, slice-major; a block contracts only its slice
+  // of the (tap, channel) steps and stores raw partial sums to the workspace (conv_splitk.hip reduces them).
+  const int tiles_all = p.n_batch * p.n_head * m_tiles * n_tiles;
+  const int slice = logical / tiles_all;
+  logical -= slice * tiles_all;
   int z, mt_i, nt_i;
   tile_coords(logical, m_tiles, n_tiles, z, mt_i, nt_i);
   const int zb = z / p.n_head;
@@ -91,7 +96,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
 
   const int cpt = p.C_in / BK;   // 32-channel steps per tap
   const int cp0 = p.C_in0 / BK;  // ... of which from in0 (== cpt without a concat input)
-  const int n_steps = p.n_taps * cpt;
+  const int steps_all = p.n_taps * cpt;  // 32-deep steps of the whole contraction
+  const int per_slice = (steps_all + ksplit - 1) / ksplit;
+  const int s_begin = slice * per_slice;
+  const int n_steps = max(0, min(steps_all, s_begin + per_slice) - s_begin);  // steps of this block
 
   // ---- operand cursors (run ahead of the MFMA phase; only load() touches them)
   const int c4 = tid & 7;     // 16-B piece of the 128-B line
@@ -119,18 +127,30 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     }
     left = seg == 0 ? cp0 : cpt - cp0;
   };
-  a_setup(0, 0);
+  {
+    // first step of this block: (tap, input tensor, 32-channel chunk inside it)
+    cur_tap = s_begin / cpt;
+    const int within = s_begin - cur_tap * cpt;
+    cur_seg = within >= cp0 ? 1 : 0;
+    const int chunk = cur_seg ? within - cp0 : within;
+    a_setup(min(cur_tap, p.n_taps - 1), cur_seg);
+#pragma unroll
+    for (int i = 0; i < C::A_LD; ++i) aptr[i] += abump[i] * chunk;
+    left -= chunk;
+  }
 
   const float* bptr[C::B_LD];  // WPL: 16-B piece c4 of the row's current 128-B plane line; else fp32 row + 4 c4
 #pragma unroll
   for (int i = 0; i < C::B_LD; ++i) {
     const int n = min(n0 + lrow + 32 * i, p.N - 1);  // columns >= N are computed on a clamped row, never stored
     if constexpr (WPL)
-      bptr[i] = reinterpret_cast<const float*>(p.w_hi) + ((int64_t)n * n_steps * 32 + c4 * 4);
+      bptr[i] = reinterpret_cast<const float*>(p.w_hi) + ((int64_t)n * steps_all * 32 + c4 * 4);
     else
       bptr[i] = p.w + (int64_t)zb * p.w_bs + (int64_t)zh * p.w_hs + (int64_t)n * p.ldw + c4 * 4;
   }
 
+#pragma unroll
+  for (int i = 0; i < C::B_LD; ++i) bptr[i] += (int64_t)s_begin * BK;
   int bbump = BK;  // floats per step (0 once the cursor is parked)
   struct Regs {
     float4 pa[C::A_LD];
@@ -377,7 +397,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
       cursor_advance();
       __syncthreads();
     }
-    conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+    if (ksplit > 1) splitk_store<MT, NT>(p, acc, slice, z, t0, n0, wm0, wn0, lane);
+    else conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
     return;
   }
 
@@ -405,42 +426,43 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     compute(1);
   }
 
-  conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
+  if (ksplit > 1) splitk_store<MT, NT>(p, acc, slice, z, t0, n0, wm0, wn0, lane);
+  else conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
 }
 
 template <class C, int ACT, bool WPL>
-int launch_fast3(const SrnConvParams& p, hipStream_t stream) {
+int launch_fast3(const SrnConvParams& p, hipStream_t stream, const int ksplit) {
   constexpr int SMEM = C::SMEM_BYTES;
   static SrnSmemAttr smem_attr;
   if (const int e = smem_attr.ensure(reinterpret_cast<const void*>(&conv_fast_kernel<C, ACT, WPL>), SMEM)) return e;
   const int m_tiles = (p.T_out + C::BM - 1) / C::BM;
   const int n_tiles = (p.N + C::BN - 1) / C::BN;
-  const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles;
+  const int64_t blocks = (int64_t)p.n_batch * p.n_head * m_tiles * n_tiles * ksplit;
   SRN_CHECK_ARG(blocks > 0 && blocks < (1ll << 31), "conv_fast: bad grid %lld", (long long)blocks);
   hipLaunchKernelGGL((conv_fast_kernel<C, ACT, WPL>), dim3((unsigned)blocks), dim3(256), SMEM, stream, p, m_tiles,
-                     n_tiles);
+                     n_tiles, ksplit);
   SRN_CHECK_LAUNCH();
   return 1;
 }
 
 template <class C, int ACT>
-int launch_fast2(const SrnConvParams& p, bool wpl, hipStream_t stream) {
-  if constexpr (C::PREC == 0) return launch_fast3<C, ACT, false>(p, stream);  // fp32: plain weight rows
-  else return wpl ? launch_fast3<C, ACT, true>(p, stream) : launch_fast3<C, ACT, false>(p, stream);
+int launch_fast2(const SrnConvParams& p, bool wpl, hipStream_t stream, int ks) {
+  if constexpr (C::PREC == 0) return launch_fast3<C, ACT, false>(p, stream, ks);  // fp32: plain weight rows
+  else return wpl ? launch_fast3<C, ACT, true>(p, stream, ks) : launch_fast3<C, ACT, false>(p, stream, ks);
 }
 
 template <class C>
-int launch_fast(const SrnConvParams& p, bool wpl, hipStream_t stream) {
-  if (p.pro_act == SRN_ACT_NONE) return launch_fast2<C, SRN_ACT_NONE>(p, wpl, stream);
-  if (p.pro_act == SRN_ACT_LEAKY) return launch_fast2<C, SRN_ACT_LEAKY>(p, wpl, stream);
-  return launch_fast2<C, -1>(p, wpl, stream);
+int launch_fast(const SrnConvParams& p, bool wpl, hipStream_t stream, int ks = 1) {
+  if (p.pro_act == SRN_ACT_NONE) return launch_fast2<C, SRN_ACT_NONE>(p, wpl, stream, ks);
+  if (p.pro_act == SRN_ACT_LEAKY) return launch_fast2<C, SRN_ACT_LEAKY>(p, wpl, stream, ks);
+  return launch_fast2<C, -1>(p, wpl, stream, ks);
 }
 
 }  // namespace
 
 // Returns 1 if the launch was handled, 0 if the shape is not eligible (caller falls back to the generic kernel),
 // < 0 on error.  `p` has been validated and defaulted by srn_conv_gemm.
-int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
+int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit) {
   if (p.w_nmajor) return 0;
   if (p.C_in % BK != 0 || p.C_in0 % BK != 0) return 0;
   const bool f32 = p.precision != SRN_PREC_BF16X3;
@@ -448,6 +470,10 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream) {
   if (!wpl) {
     // fp32 B rows walked contiguously over (tap, channel): needs the packed [tap][C_in] row layout, all of it live
     if (p.C_w != p.C_in || p.ldw < p.n_taps * p.C_in) return 0;
+  }
+  if (ksplit > 1) {  // split-K launches always take the 64 x 64 tile (they exist because the grid is small)
+    if (f32) return launch_fast<FCfg<64, 64, 32, 32, 2, 0>>(p, false, stream, ksplit);
+    return launch_fast<FCfg<64, 64, 32, 32>>(p, wpl, stream, ksplit);
   }
   if (f32) {
     switch (tile) {

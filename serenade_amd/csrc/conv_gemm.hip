@@ -518,6 +518,15 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
 
   int tile = p.tile > 0 ? p.tile : pick_tile(p);
   if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
+  if (p.ws != nullptr && p.tile <= 0 && p.no_halo != 3) {
+    // small grids with a deep contraction (B = 1 / short utterances): slice K over extra workgroups, reduce after
+    const int ks = srn_splitk_plan(p);
+    if (ks > 1 && p.ws_bytes >= srn_splitk_bytes(p, ks)) {
+      const int r = srn_conv_fast_try(p, 4, stream, ks);
+      if (r < 0) return r;
+      if (r == 1) return srn_splitk_reduce(p, ks, stream);
+    }
+  }
   if (p.no_halo != 1 && p.no_halo != 3) {
     // thin convs (<= 64 channels in and out): persistent strip kernel with LDS-resident weights
     const int r = srn_conv_strip_try(p, stream);
@@ -549,4 +558,14 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
   }
   srn_set_error("conv_gemm: unknown tile id %d", tile);
   return -1;
+}
+
+extern "C" int64_t srn_conv_gemm_workspace_bytes(const SrnConvParams* pp) {
+  if (pp == nullptr) return 0;
+  SrnConvParams p = *pp;
+  if (p.C_in0 <= 0 || p.C_in0 > p.C_in) p.C_in0 = p.C_in;
+  if (p.C_w <= 0 || p.C_w > p.C_in) p.C_w = p.C_in;
+  if (p.n_head <= 0 || p.n_batch <= 0 || p.T_out <= 0 || p.N <= 0 || p.C_in <= 0 || p.n_taps <= 0) return 0;
+  const int ks = srn_splitk_plan(p);
+  return ks > 1 ? srn_splitk_bytes(p, ks) : 0;
 }

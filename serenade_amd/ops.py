@@ -12,11 +12,16 @@ import torch
 from . import _lib
 from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_LEAKY, POST_NONE, POST_RELU,  # noqa: F401
                    POST_TANH,
-                   RES_ADD, RES_AXPY, RES_NONE, SrnConvParams, check)
+                   RES_ADD, RES_AXPY, RES_NONE, SrnConvParams, SrnResUnitParams, check)
 
 
 DEFAULT_PRECISION = _lib.PREC_FP32  # contraction arithmetic of ops built without an explicit precision
 NO_HALO = False  # True: force the generic kernel everywhere (A/B timing)
+# Split-K for launches whose tile grid cannot fill the chip (B = 1 / short utterances; conv_splitk.hip): every ConvOp
+# is handed the per-device workspace below and the library decides per call.  SERENADE_AMD_SPLITK=0 turns it off.
+SPLITK = os.environ.get("SERENADE_AMD_SPLITK", "1") != "0"
+SPLITK_WS_BYTES = 32 << 20  # upper bound of the library's need (<= 192 tiles of 64 x 64, <= 8 slices, fp32)
+_SPLITK_WS = {}
 PROFILE = None  # set to a list by bench.py to collect (start event, end event, op) per conv_gemm launch
 
 
@@ -87,6 +92,11 @@ class ConvOp:
             if isinstance(w, torch.Tensor) and w.is_cuda and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor:
                 self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw)
                 p.w_hi = self._wplanes[0].data_ptr()
+        if SPLITK and isinstance(out, (torch.Tensor, tuple)):
+            o = out[0] if isinstance(out, tuple) else out
+            if o.is_cuda and self._fn and _lib.lib().srn_conv_gemm_workspace_bytes(ctypes.byref(p)) > 0:
+                ws = splitk_workspace(o.device)  # one per device: the ops of a plan run back to back on one stream
+                p.ws, p.ws_bytes = ws.data_ptr(), ws.numel()
 
     def __call__(self, stream=None):
         if PROFILE is not None and stream is None:
@@ -98,6 +108,43 @@ class ConvOp:
             PROFILE.append((s, e, self))
             return
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
+
+
+def splitk_workspace(device):
+    key = str(device)
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+    return _SPLITK_WS[key]
+
+
+class ResUnitOp:
+    """A prebuilt srn_hifigan_resunit call: one fused HiFi-GAN residual unit (see include/serenade_hip.h)."""
+
+    __slots__ = ("p", "kw", "_fn", "_wplanes")
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self._build(**kw)
+
+    def _build(self, *, x, w1, b1, w2, b2, out, n_batch, T, C, k, dilation, slope, res2=None, post_div=0.0,
+               precision=None):
+        p = SrnResUnitParams()
+        p.n_batch, p.T, p.C, p.k, p.dilation, p.slope = int(n_batch), int(T), int(C), int(k), int(dilation), float(slope)
+        p.x, p.x_bs = _ptr(x), int(T) * int(C)
+        p.w1, p.b1, p.w2, p.b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
+        p.res2, p.res2_bs = _ptr(res2), int(T) * int(C)
+        p.post_div = float(post_div)
+        p.out, p.out_bs = _ptr(out), int(T) * int(C)
+        p.precision = int(DEFAULT_PRECISION if precision is None else precision)
+        self._wplanes = None
+        if p.precision == _lib.PREC_BF16X3 and w1.is_cuda:
+            self._wplanes = (weight_planes(w1, C, k, C, k * C), weight_planes(w2, C, k, C, k * C))
+            p.w1_hi, p.w2_hi = self._wplanes[0][0].data_ptr(), self._wplanes[1][0].data_ptr()
+        self.p = p
+        self._fn = _lib.lib().srn_hifigan_resunit
+
+    def __call__(self, stream=None):
+        check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_hifigan_resunit")
 
 
 _WPLANES = {}  # (data_ptr, version, shape, ...) -> (planes, weight) bf16 weight planes, split once per weight VALUE

@@ -159,6 +159,9 @@ class HiFiGANGenerator(_Packed):
         return self._run_cl(c.detach().to(torch.float32).contiguous())
 
 
+FUSED_UNIT_CHANNELS = (32, 64)  # stage widths whose residual units run as one fused launch (srn_hifigan_resunit)
+
+
 class HiFiGANPlan:
     """Buffers + op list of one generator forward for (B, T).  Input: self.c_in (B, T, in_ch) channels-last;
     output: self.wave (B, T * hop)."""
@@ -211,7 +214,12 @@ class HiFiGANPlan:
                             fin.update(res2=acc, res2_bs=Tn * C, ld_res2=C)
                         if j == nb - 1:
                             fin.update(post=POST_DIV, post_div=float(nb))
-                    if "w2" in cv:
+                    if "w2" in cv and C in FUSED_UNIT_CHANNELS and (cv["k"] - 1) * cv["d"] <= 50 and cv["k"] % 2 == 1:
+                        # thin stage: the whole unit in one launch (resunit.hip); stage sum / mean in its epilogue
+                        ol.append(ops.ResUnitOp(x=x, w1=cv["w1"], b1=cv["b1"], w2=cv["w2"], b2=cv["b2"], out=dst,
+                                                n_batch=B, T=Tn, C=C, k=cv["k"], dilation=cv["d"], slope=slope,
+                                                res2=fin.get("res2"), post_div=fin.get("post_div", 0.0)))
+                    elif "w2" in cv:
                         ol.append(conv(x, C, Tn, cv["w1"], cv["b1"], xt, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
                                        pro_act=ACT_LEAKY, pro_slope=slope))
                         ol.append(conv(xt, C, Tn, cv["w2"], cv["b2"], dst, C, Tn, ops.conv_taps(cv["k"], 1),

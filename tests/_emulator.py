@@ -262,20 +262,39 @@ def emul_call(name, a):
         raise NotImplementedError(name)
 
 
+def emul_resunit(kw):
+    """srn_hifigan_resunit: y = conv2(lrelu(conv1(lrelu(x)))) + x [+ res2] [/ post_div], channels-last views"""
+    g = kw.get
+    B, T, C, k, d, slope = g("n_batch"), g("T"), g("C"), g("k"), g("dilation"), g("slope")
+    x = _v(g("x"), B * T * C).reshape(B, T, C)
+    w1 = g("w1").reshape(C, k, C).permute(0, 2, 1)  # packed [C_out][k][C_in] -> torch (C_out, C_in, k)
+    w2 = g("w2").reshape(C, k, C).permute(0, 2, 1)
+    xt = F.conv1d(F.leaky_relu(x.transpose(1, 2), slope), w1, g("b1"), padding=(k - 1) // 2 * d, dilation=d)
+    xt = F.conv1d(F.leaky_relu(xt, slope), w2, g("b2"), padding=(k - 1) // 2)
+    y = xt.transpose(1, 2) + x
+    if g("res2") is not None:
+        y = y + _v(g("res2"), B * T * C).reshape(B, T, C)
+    if g("post_div", 0.0) not in (0.0, 1.0):
+        y = y / g("post_div")
+    _v(g("out"), B * T * C).reshape(B, T, C)[:] = y
+
+
 class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
     def __enter__(self):
         from serenade_amd import sifigan
         self._mods = (models, vocoder, sifigan)
-        self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods])
+        self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods],
+                       ops.ResUnitOp.__call__)
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)
+        ops.ResUnitOp.__call__ = lambda self_, stream=None: emul_resunit(self_.kw)
         ops.CallOp.__call__ = lambda self_, stream=None: emul_call(self_.name, self_.targs)
         for m in self._mods:
             m._require_cuda = lambda *a, **k: None
         return self
 
     def __exit__(self, *exc):
-        ops.ConvOp.__call__, ops.CallOp.__call__, guards = self._saved
+        ops.ConvOp.__call__, ops.CallOp.__call__, guards, ops.ResUnitOp.__call__ = self._saved
         for m, g in zip(self._mods, guards):
             m._require_cuda = g

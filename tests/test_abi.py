@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_error_reporting_without_gpu(lib):
-    assert lib.srn_abi_version() == 1
+    assert lib.srn_abi_version() == 2
     assert lib.srn_conv_gemm(None, None) == -1
     assert b"null params" in lib.srn_last_error()
     p = _lib.SrnConvParams()
@@ -43,18 +43,20 @@ def test_error_reporting_without_gpu(lib):
     assert b"null in0" in lib.srn_last_error()
 
 
-def test_struct_layout_matches_c(tmp_path):
-    fields = [f[0] for f in _lib.SrnConvParams._fields_]
+@pytest.mark.parametrize("name", ["SrnConvParams", "SrnResUnitParams"])
+def test_struct_layout_matches_c(tmp_path, name):
+    cls = getattr(_lib, name)
+    fields = [f[0] for f in cls._fields_]
     probe = tmp_path / "probe.c"
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){',
-             'printf("%zu\\n", sizeof(SrnConvParams));']
+             f'printf("%zu\\n", sizeof({name}));']
     for f in fields:
-        lines.append(f'printf("%zu\\n", offsetof(SrnConvParams, {f}));')
+        lines.append(f'printf("%zu\\n", offsetof({name}, {f}));')
     lines.append("return 0;}")
     probe.write_text("\n".join(lines))
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-o", str(exe), str(probe)])
     out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    assert out[0] == ctypes.sizeof(_lib.SrnConvParams)
+    assert out[0] == ctypes.sizeof(cls)
     for f, off in zip(fields, out[1:]):
-        assert getattr(_lib.SrnConvParams, f).offset == off, f
+        assert getattr(cls, f).offset == off, f

@@ -1,0 +1,156 @@
+"""GPU tests of the two round-2 launch-level kernels, through the C ABI, in both contraction modes:
+
+* srn_hifigan_resunit (resunit.hip): one fused HiFi-GAN residual unit vs torch.nn.functional.conv1d on the same
+  weights (reference semantics: serenade/vocoder/layers/residual_block.py:243-258), every (C, k, dilation) of the path,
+  sequence ends inside / across tiles, with and without the stage sum / mean epilogue;
+* split-K (conv_splitk.hip): small tile grids with deep contractions take the sliced path (asserted through
+  srn_conv_gemm_workspace_bytes) and agree with the executable spec, with every epilogue feature it reduces.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import serenade_amd
+from serenade_amd import _lib, ops
+from tests import _emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+def precision(request):
+    serenade_amd.set_precision(request.param)
+    yield request.param
+    serenade_amd.set_precision("bf16x3")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def tol():
+    return 2e-5 if serenade_amd.get_precision() == "fp32" else 1e-4
+
+
+def nerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(*s, seed=0, scale=1.0):
+    return torch.from_numpy((scale * np.random.default_rng(seed).standard_normal(s)).astype(np.float32))
+
+
+def ref_unit(x, w1, b1, w2, b2, k, d, slope, res2=None, div=0.0):
+    """x (B, T, C) channels-last; w (C_out, C_in, k) torch layout; fp64 reference"""
+    xd = x.double().transpose(1, 2)
+    xt = F.conv1d(F.leaky_relu(xd, slope), w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+    xt = F.conv1d(F.leaky_relu(xt, slope), w2.double(), b2.double(), padding=(k - 1) // 2)
+    y = (xt + xd).transpose(1, 2)
+    if res2 is not None:
+        y = y + res2.double()
+    if div not in (0.0, 1.0):
+        y = y / div
+    return y
+
+
+@pytest.mark.parametrize("C", [32, 64])
+@pytest.mark.parametrize("k,d", [(3, 1), (3, 5), (7, 3), (11, 1), (11, 5), (5, 2)])
+def test_resunit_vs_conv1d(dev, C, k, d):
+    slope = 0.1
+    for case, (B, T, with_sum) in enumerate([(2, 37, False), (1, 1000, True), (3, 2 * (256 - (k - 1)) + 1, True)]):
+        x = rnd(B, T, C, seed=10 * case + 1)
+        w1 = rnd(C, C, k, seed=10 * case + 2, scale=1.0 / np.sqrt(C * k))
+        w2 = rnd(C, C, k, seed=10 * case + 3, scale=1.0 / np.sqrt(C * k))
+        b1, b2 = rnd(C, seed=10 * case + 4, scale=0.1), rnd(C, seed=10 * case + 5, scale=0.1)
+        res2 = rnd(B, T, C, seed=10 * case + 6) if with_sum else None
+        div = 3.0 if with_sum else 0.0
+        ref = ref_unit(x, w1, b1, w2, b2, k, d, slope, res2, div)
+        g = lambda t: None if t is None else t.to(dev)
+        out = torch.full((B, T, C), float("nan"), device=dev)
+        guard = torch.zeros(64, device=dev)  # allocated right after `out`: catches writes past the end
+        op = ops.ResUnitOp(x=g(x), w1=ops.pack_conv_weight(g(w1)), b1=g(b1), w2=ops.pack_conv_weight(g(w2)), b2=g(b2),
+                           out=out, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope, res2=g(res2), post_div=div)
+        op()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), f"C={C} k={k} d={d} case {case}: unwritten / non-finite outputs"
+        assert nerr(out, ref) < tol(), f"C={C} k={k} d={d} case {case}"
+        assert guard.abs().max().item() == 0
+
+
+def test_resunit_matches_the_unfused_pair_and_rejects_bad_args(dev):
+    """same unit as two srn_conv_gemm launches (the round-1 path) and as one fused launch"""
+    B, T, C, k, d, slope = 2, 700, 64, 7, 3, 0.1
+    x, b1, b2 = rnd(B, T, C, seed=1).to(dev), rnd(C, seed=4, scale=0.1).to(dev), rnd(C, seed=5, scale=0.1).to(dev)
+    w1 = ops.pack_conv_weight(rnd(C, C, k, seed=2, scale=0.05).to(dev))
+    w2 = ops.pack_conv_weight(rnd(C, C, k, seed=3, scale=0.05).to(dev))
+    xt, y0, y1 = (torch.zeros(B, T, C, device=dev) for _ in range(3))
+    conv = lambda i, w, b, o, taps, **kw: ops.ConvOp(in0=i, w=w, out=o, n_batch=B, T_in=T, T_out=T, C_in=C, N=C,
+                                                      in0_bs=T * C, ld_in0=C, ldw=w.shape[1], out_bs=T * C, ld_out=C,
+                                                      bias=b, taps=taps, pro_act=ops.ACT_LEAKY, pro_slope=slope, **kw)
+    conv(x, w1, b1, xt, ops.conv_taps(k, d))()
+    conv(xt, w2, b2, y0, ops.conv_taps(k, 1), res=x, res_mode=ops.RES_ADD, res_bs=T * C, ld_res=C)()
+    ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=y1, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope)()
+    torch.cuda.synchronize()
+    assert nerr(y1, y0) < tol()
+    with pytest.raises(RuntimeError, match="32 or 64"):
+        ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=y1, n_batch=B, T=T, C=128, k=k, dilation=d, slope=slope)()
+    with pytest.raises(RuntimeError, match="alias"):
+        ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=x, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope)()
+
+
+class Mirror:
+    """CPU tensors <-> device clones, so one kw dict drives the kernel and the spec"""
+
+    def __init__(self, dev):
+        self.dev, self.map = dev, {}
+
+    def __call__(self, v):
+        if isinstance(v, torch.Tensor):
+            if id(v) not in self.map:
+                self.map[id(v)] = (v, v.to(self.dev))
+            return self.map[id(v)][1]
+        if isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], torch.Tensor):
+            return (self(v[0]), v[1])
+        return v
+
+
+@pytest.mark.parametrize("case", ["plain_gn", "residual_inplace", "axpy_masked", "strided_leaky_concat"])
+def test_splitk_path_matches_spec(dev, case):
+    B, T, K, N = 1, 150, 128, 160  # 3 x 3 tiles of 64 x 64: the grid cannot fill the chip; 3 taps x 4 chunks
+    taps = [-1, 0, 1]
+    kw = dict(in0=rnd(B, T, K, seed=1), w=rnd(N, 3 * K, seed=2, scale=0.05), bias=rnd(N, seed=3), n_batch=B, T_in=T,
+              T_out=T, C_in=K, N=N, in0_bs=T * K, ld_in0=K, ldw=3 * K, out_bs=T * N, ld_out=N, taps=taps,
+              out=torch.zeros(B, T, N))
+    if case == "plain_gn":
+        kw.update(N=160, gn_partials=torch.zeros(B, (T + 31) // 32, N // 32, 2), alpha=0.5)
+    elif case == "residual_inplace":
+        o = rnd(B, T, N, seed=4)
+        kw.update(out=o, res=o, res_mode=ops.RES_ADD, res_bs=T * N, ld_res=N, post=ops.POST_DIV, post_div=3.0,
+                  res2=rnd(B, T, N, seed=5), res2_bs=T * N, ld_res2=N)
+    elif case == "axpy_masked":
+        o = rnd(B, T, N, seed=6)
+        kw.update(out=o, res=o, res_mode=ops.RES_AXPY, beta=0.1, res_bs=T * N, ld_res=N,
+                  len_out=torch.tensor([101], dtype=torch.int32), len_in=torch.tensor([120], dtype=torch.int32))
+    else:
+        K0 = 64
+        kw.update(in0=rnd(B, T, K0, seed=7), in1=rnd(B, T, K - K0, seed=8), C_in0=K0, in0_bs=T * K0, ld_in0=K0,
+                  in1_bs=T * (K - K0), ld_in1=K - K0, pro_act=ops.ACT_LEAKY, pro_slope=0.2,
+                  out=torch.zeros(B, 2 * T, N), out_bs=2 * T * N, out_t_stride=2, out_t_off=1)
+    m = Mirror(dev)
+    gpu = {k: m(v) for k, v in kw.items()}
+    op = ops.ConvOp(**gpu)
+    need = _lib.lib().srn_conv_gemm_workspace_bytes(ctypes.byref(op.p))
+    assert need > 0 and op.p.ws and op.p.ws_bytes >= need, "this shape must take the split-K path"
+    op()
+    torch.cuda.synchronize()
+    _emulator.emul_conv(kw)
+    for c, g_ in m.map.values():
+        if c.is_floating_point():
+            assert nerr(g_, c) < tol(), case
