@@ -169,6 +169,9 @@ def recorded_traffic(precision):
 
 def op_bytes(kw):
     """operand bytes one contraction launch must move once: A + B read, output written, residuals read"""
+    if "dilation" in kw:  # fused HiFi-GAN residual unit: x in, y out, two weight tensors (+ the stage sum)
+        t = kw["n_batch"] * kw["T"] * kw["C"] * 4
+        return t * (2 + (kw.get("res2") is not None)) + 2 * kw["k"] * kw["C"] * kw["C"] * 4
     Z = kw["n_batch"] * kw.get("n_head", 1)
     taps = len(kw.get("taps", (0,)))
     n_out = kw.get("N_out", 0) or kw["N"]

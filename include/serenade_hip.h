@@ -216,11 +216,40 @@ int srn_conv2d_bn_relu(const float* x, const float* w, const float* bn_scale, co
 int srn_gru_last(const float* xs, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* h,
                  int B, int T, int I, int H, void* stream);
 
+/* The same GRU with the input projection hoisted out: gi (B, T, 3H) = x W_ih^T + b_ih comes from one srn_conv_gemm
+ * over all (b, t) rows; this call runs only the recurrence h -> W_hh h.  w_hh_t (H, 3H) = W_hh transposed. */
+int srn_gru_recur_last(const float* gi, const float* w_hh_t, const float* b_hh, float* h, int B, int T, int H,
+                       void* stream);
+
 /* StyleTokenLayer (style_encoder.py:235-252 + gst/attention.py:110-184,298-300): q (B, Dq) -> out (B, F).
  * embs (n_tok, dk_in) raw (tanh applied inside). */
 int srn_style_token_attention(const float* ref, const float* embs, const float* wq, const float* bq, const float* wk,
                               const float* bk, const float* wv, const float* bv, const float* wo, const float* bo,
                               float* out, int B, int Dq, int n_tok, int dk_in, int F, int n_head, void* stream);
+
+/* The same layer with its input-independent parts formed at weight-packing time: k, v (n_tok, F) =
+ * tanh(embs) W_k^T + b_k / W_v^T + b_v; wq_t (Dq, F), wo_t (F, F) = W_q, W_out transposed. */
+int srn_style_token_attention_kv(const float* ref, const float* wq_t, const float* bq, const float* k, const float* v,
+                                 const float* wo_t, const float* bo, float* out, int B, int Dq, int n_tok, int F,
+                                 int n_head, void* stream);
+
+/*
+ * Feature front-end in front of the hot path (serenade/bin/preprocess.py:126-203: `loudness_extract`,
+ * `logmelfilterbank`; their arithmetic lives in the un-vendored librosa, restated in oracle/features_oracle.py --
+ * parity unpinned).  The STFT itself is srn_conv_gemm over the reflect-padded signal viewed as rows of 16 samples with
+ * the window x DFT basis as weights; its output rows are [re(0..n_bins-1) | im(0..n_bins-1) | pad] with stride ld.
+ */
+/* numpy.pad(x, pad, mode="reflect") per batch row, zero-filled up to ld: x (B, n) -> out (B, ld). */
+int srn_reflect_pad(const float* x, float* out, int B, int n, int pad, int ld, void* stream);
+/* out (frames, n_mels) = log_b(max(eps, |spec| @ mel^T)); mel_t (n_bins, n_mels) = filterbank transposed;
+ * log_mode 10 / 2 / 0 (natural)  (preprocess.py:176-203). */
+int srn_logmel(const float* spec, const float* mel_t, float* out, int64_t frames, int n_bins, int ld, int n_mels,
+               float eps, int log_mode, void* stream);
+/* out (B, frames) = log(mean_f 10^((max(10 log10(max(amin, |spec|^2)), max_db(utterance) - top_db) + a_weight_db[f])
+ * / 20) + add_eps)  (preprocess.py:126-137: power_to_db -> perceptual_weighting -> db_to_amplitude -> mean -> log).
+ * gmax_ws: B uint32 of scratch. */
+int srn_loudness(const float* spec, const float* a_weight_db, uint32_t* gmax_ws, float* out, int B, int frames,
+                 int n_bins, int ld, float amin, float top_db, float add_eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -711,6 +711,13 @@ class StyleEncoder(_Packed):
                 P["w" + nm[0]] = sd[f"stl.mha.linear_{nm}.weight"]
                 P["b" + nm[0]] = sd[f"stl.mha.linear_{nm}.bias"]
             P["embs"] = sd["stl.gst_embs"]
+            # input-independent parts of the tail, formed once here (like the weight-norm / BatchNorm folds): the
+            # style tokens' keys and values, and transposed matrices for coalesced matvecs
+            toks = torch.tanh(P["embs"])
+            P["tok_k"] = (toks @ P["wk"].t() + P["bk"]).contiguous()
+            P["tok_v"] = (toks @ P["wv"].t() + P["bv"]).contiguous()
+            P["wq_t"], P["wo_t"] = P["wq"].t().contiguous(), P["wo"].t().contiguous()
+            P["w_hh_t"] = P["w_hh"].t().contiguous()
             self._packed = P
         return self._packed
 
@@ -748,10 +755,18 @@ class StyleEncoder(_Packed):
                 ol.append(ConvOp(**kw))
             cur, H, W, Ci = y, Ho, Wo, Co
         ref = torch.zeros(B, self.gru_units, device=dev, dtype=torch.float32)
-        ol.append(ops.gru_last_op(cur, P["w_ih"], P["w_hh"], P["b_ih"], P["b_hh"], ref, B, H, W * Ci, self.gru_units))
-        ol.append(ops.style_token_attention_op(ref, P["embs"], P["wq"], P["bq"], P["wk"], P["bk"], P["wv"], P["bv"],
-                                               P["wo"], P["bo"], out, B, self.gru_units, self.gst_tokens,
-                                               P["embs"].shape[1], self.gst_token_dim, self.gst_heads))
+        # GRU: input projection of all (b, t) rows as one contraction over the chip, then the short recurrence
+        G3, I = 3 * self.gru_units, W * Ci
+        if I % 4 == 0:
+            gi = torch.zeros(B, H, G3, device=dev, dtype=torch.float32)
+            ol.append(ConvOp(in0=cur, w=P["w_ih"], out=gi, n_batch=1, T_in=B * H, T_out=B * H, C_in=I, N=G3, ld_in0=I,
+                             ldw=I, ld_out=G3, bias=P["b_ih"]))
+            ol.append(ops.gru_recur_last_op(gi, P["w_hh_t"], P["b_hh"], ref, B, H, self.gru_units))
+        else:
+            ol.append(ops.gru_last_op(cur, P["w_ih"], P["w_hh"], P["b_ih"], P["b_hh"], ref, B, H, I, self.gru_units))
+        ol.append(ops.style_token_attention_kv_op(ref, P["wq_t"], P["bq"], P["tok_k"], P["tok_v"], P["wo_t"], P["bo"],
+                                                  out, B, self.gru_units, self.gst_tokens, self.gst_token_dim,
+                                                  self.gst_heads))
         self._last_ref = ref
         return ol
 

@@ -249,6 +249,43 @@ def emul_call(name, a):
             n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
             hh = (1 - z) * n + z * hh
         _v(h, B * H).reshape(B, H)[:] = hh
+    elif name == "srn_reflect_pad":
+        x, out, B, n, pad, ld = a
+        xv = _v(x, B * n).reshape(B, n)
+        ov = _v(out, B * ld).reshape(B, ld)
+        ov[:] = 0
+        ov[:, :n + 2 * pad] = F.pad(xv.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    elif name == "srn_logmel":
+        spec, mel_t, out, frames, nb, ld, n_mels, eps, mode = a
+        sv = _v(spec, frames * ld).reshape(frames, ld)
+        mag = torch.sqrt(sv[:, :nb] ** 2 + sv[:, nb:2 * nb] ** 2)
+        m = torch.clamp(mag @ mel_t, min=eps)
+        _v(out, frames * n_mels).reshape(frames, n_mels)[:] = {10: torch.log10, 2: torch.log2, 0: torch.log}[mode](m)
+    elif name == "srn_loudness":
+        spec, aw, ws, out, B, frames, nb, ld, amin, top_db, add_eps = a
+        sv = _v(spec, B * frames * ld).reshape(B, frames, ld)
+        p = sv[..., :nb] ** 2 + sv[..., nb:2 * nb] ** 2
+        db = 10 * torch.log10(torch.clamp(p, min=amin))
+        db = torch.maximum(db, db.amax(dim=(1, 2), keepdim=True) - top_db) + aw
+        _v(out, B * frames).reshape(B, frames)[:] = torch.log(torch.pow(10.0, 0.05 * db).mean(dim=-1) + add_eps)
+    elif name == "srn_gru_recur_last":
+        gi_all, whh_t, bhh, h, B, T, H = a
+        gv = _v(gi_all, B * T * 3 * H).reshape(B, T, 3 * H)
+        hh = torch.zeros(B, H)
+        for t in range(T):
+            gi, gh = gv[:, t], hh @ whh_t + bhh
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            hh = (1 - z) * n + z * hh
+        _v(h, B * H).reshape(B, H)[:] = hh
+    elif name == "srn_style_token_attention_kv":
+        ref, wq_t, bq, k, v, wo_t, bo, out, B, Dq, n_tok, Fd, nh = a
+        q = _v(ref, B * Dq).reshape(B, Dq) @ wq_t + bq
+        dk = Fd // nh
+        sc = torch.einsum("bhd,thd->bht", q.view(B, nh, dk), k.view(n_tok, nh, dk)) / math.sqrt(dk)
+        ctx = torch.einsum("bht,thd->bhd", torch.softmax(sc, -1), v.view(n_tok, nh, dk)).reshape(B, Fd)
+        _v(out, B * Fd).reshape(B, Fd)[:] = ctx @ wo_t + bo
     elif name == "srn_style_token_attention":
         ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok, dk_in, Fd, nh = a
         toks = torch.tanh(embs)
@@ -283,8 +320,8 @@ class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
     def __enter__(self):
-        from serenade_amd import sifigan
-        self._mods = (models, vocoder, sifigan)
+        from serenade_amd import features, sifigan
+        self._mods = (models, vocoder, sifigan, features)
         self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods],
                        ops.ResUnitOp.__call__)
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)

@@ -128,7 +128,7 @@ ALL_TILES = (0, 1, 2, 3, 4, 5)
 
 def test_library_exports_and_error_path(dev):
     lib = _lib.lib()
-    assert lib.srn_abi_version() == 1
+    assert lib.srn_abi_version() == 2
     rc = lib.srn_conv_gemm(None, None)
     assert rc != 0 and b"null" in lib.srn_last_error()
 
@@ -379,6 +379,14 @@ def test_gst_kernels(dev):
          rnd(256, 64, seed=63) / 8, 0.1 * rnd(256, seed=64), rnd(256, 64, seed=65) / 8, 0.1 * rnd(256, seed=66),
          rnd(256, 256, seed=67) / 16, 0.1 * rnd(256, seed=68), torch.zeros(2, 256), 2, 128, 50, 64, 256, 4]
     assert _run_call(dev, "srn_style_token_attention", a) < KTOL.k
+    # round-2 forms: recurrence on a precomputed input projection, attention on precomputed K / V
+    e = _run_call(dev, "srn_gru_recur_last", [rnd(3, 5, 384, seed=70), rnd(128, 384, seed=71) / 11,
+                                              0.1 * rnd(384, seed=72), torch.zeros(3, 128), 3, 5, 128])
+    assert e < KTOL.k
+    a = [rnd(2, 128, seed=73), rnd(128, 256, seed=74) / 11, 0.1 * rnd(256, seed=75), rnd(50, 256, seed=76),
+         rnd(50, 256, seed=77), rnd(256, 256, seed=78) / 16, 0.1 * rnd(256, seed=79), torch.zeros(2, 256), 2, 128, 50,
+         256, 4]
+    assert _run_call(dev, "srn_style_token_attention_kv", a) < KTOL.k
 
 
 # ------------------------------------------------------------------------------------------------

@@ -100,7 +100,8 @@ def test_resunit_matches_the_unfused_pair_and_rejects_bad_args(dev):
     torch.cuda.synchronize()
     assert nerr(y1, y0) < tol()
     with pytest.raises(RuntimeError, match="32 or 64"):
-        ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=y1, n_batch=B, T=T, C=128, k=k, dilation=d, slope=slope)()
+        ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=y1, n_batch=B, T=T, C=128, k=k, dilation=d, slope=slope,
+                      precision=_lib.PREC_FP32)()
     with pytest.raises(RuntimeError, match="alias"):
         ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=x, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope)()
 

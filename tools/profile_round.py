@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Produce the committed evidence behind bench.py's `roofline` object (run on the GPU box, from the repo root):
 
-    python3 tools/profile_round.py r2_a [--modes fp32,bf16x3] [--no-sq]
+    python3 tools/profile_round.py r2_a [--modes=fp32,bf16x3] [--no-sq]        (GPU box: collect + aggregate)
+    python3 tools/profile_round.py r2_a --aggregate-only                        (anywhere: re-read the collected CSVs)
+
+gpurun only brings gpurun_out/ back, so the raw rocprofv3 output lives in gpurun_out/prof_<tag>/ and the summaries
+are (re)built from it into profiles/ by the second form in the build container.
 
 For each contraction mode it profiles THE bench.py command (size sweep and CPU leg off) with rocprofv3:
   1. --kernel-trace --stats                    -> profiles/<tag>_kernel_stats_<mode>.csv
@@ -33,7 +37,12 @@ def bench_cmd(mode, steps, warmup):
             "--modes", mode]
 
 
+COLLECT = "--aggregate-only" not in sys.argv
+
+
 def rocprof(outdir, extra, cmd):
+    if not COLLECT:
+        return
     shutil.rmtree(outdir, ignore_errors=True)
     os.makedirs(outdir, exist_ok=True)
     full = ["rocprofv3"] + extra + ["--output-format", "csv", "-d", outdir, "--"] + cmd
@@ -81,7 +90,11 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
     scratch = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    record = {"build": bench.build_id(), "workload": "bench.py default: B=8 x T=1024, T_ref=256, 10 Euler steps + "
+    build_file = os.path.join(scratch, "build_id.txt")
+    if COLLECT:
+        os.makedirs(scratch, exist_ok=True)
+        open(build_file, "w").write(bench.build_id())
+    record = {"build": open(build_file).read().strip(), "workload": "bench.py default: B=8 x T=1024, T_ref=256, 10 Euler steps + "
               "HiFi-GAN (8,5,3,2); 1 warm-up + 1 timed step per counter pass", "modes": {},
               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB -> bytes; "
                         "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); contraction kernels only"}
