@@ -13,8 +13,9 @@ converted waveforms are gathered on rank 0 over RCCL inside the timed region.  R
 
 The top-level `value` / `ms_per_step` / `dtype` / `roofline` are measured in the REFERENCE's precision: exact fp32
 contraction on v_mfma_f32_32x32x2_f32.  The faster split-bf16 product mode (operands as bf16 hi+lo, 3 MFMA per
-product: inside the north-star tolerances but narrower than fp32) is timed in the same run and reported under
-`split_bf16_mode`; the north-star's other sizes under `sweep`; the CPU oracle on the host cores under `cpu_baseline`.
+product: inside the north-star tolerances but narrower than fp32) and the fp32-faithful bf16x6 emulation (exact
+three-way operand split, 6 MFMA per product) are timed in the same run and reported under `split_bf16_mode` /
+`fp32_emulated_bf16x6_mode`; the north-star's other sizes under `sweep`; the CPU oracle under `cpu_baseline`.
 """
 import argparse
 import glob
@@ -36,7 +37,10 @@ import torch.distributed as dist  # noqa: E402
 B_PER_GPU, T_SRC, T_REF, N_EULER = 8, 1024, 256, 10
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak (one MFMA pass; split-bf16 needs three)
-DTYPE = {"fp32": "f32", "bf16x3": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate"}
+DTYPE = {"fp32": "f32", "bf16x3": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate",
+         "bf16x6": "f32 emulated on bf16 MFMA: exact hi+mid+lo operand split (24 significand bits), 6 MFMA/product, "
+                   "f32 accumulate (dropped terms <= 2^-26 per product)"}
+MODE_KEY = {"fp32": "exact_fp32_mode", "bf16x3": "split_bf16_mode", "bf16x6": "fp32_emulated_bf16x6_mode"}
 
 
 def algorithmic_flops(B, T, T_ref, n):
@@ -191,8 +195,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the north-star size sweep (profiling runs)")
-    ap.add_argument("--modes", default="fp32,bf16x3", help="contraction modes to time; the first is the headline "
-                                                           "(profiling runs pass one)")
+    ap.add_argument("--modes", default="fp32,bf16x6,bf16x3", help="contraction modes to time; the first is the "
+                                                                  "headline (profiling runs pass one)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the "
                     "waveform gather even with one rank (single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--graphs", type=int, default=None, help="1/0: replay the plans as hipGraphs (default: library default)")
@@ -294,7 +298,7 @@ def main():
         gemm_ms = durs.sum()
         alg_bytes = float(sum(op_bytes(op.kw) for _, _, op in prof))
         achieved = fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+        peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         tr = recorded_traffic(precision)
         same_workload = (B_PER_GPU, T_SRC, T_REF, N_EULER) == (8, 1024, 256, 10)
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -310,9 +314,10 @@ def main():
                                                          "write_bytes_per_launch", "launches")}
             roof["traffic_record"]["current_build"] = build_id()
             roof["traffic_unit"] = "bytes/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-        if precision == "bf16x3":
-            roof["mfma_per_product"] = 3
-            roof["frac_of_split_peak"] = achieved / (peak / 3.0)
+        if precision != "fp32":
+            per = 3 if precision == "bf16x3" else 6
+            roof["mfma_per_product"] = per
+            roof["frac_of_split_peak"] = achieved / (peak / per)
         value = world * B_PER_GPU * T_SRC * args.steps / elapsed
         return {"value": value, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
                 "dtype": DTYPE[precision], "x_realtime": value / 100.0, "roofline": roof, **extra}
@@ -360,7 +365,7 @@ def main():
         if k in head:
             out.setdefault("multi_gpu", {})[k] = head[k]
     for m in modes[1:]:
-        out["split_bf16_mode" if m == "bf16x3" else "exact_fp32_mode"] = results[m]
+        out[MODE_KEY[m]] = results[m]
     if rank == 0 and world == 1 and not args.no_sweep:
         out["sweep"] = sweep()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

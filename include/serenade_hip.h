@@ -42,7 +42,10 @@ enum {
 /* arithmetic of the contraction */
 enum {
   SRN_PREC_FP32 = 0,  /* exact fp32 MFMA */
-  SRN_PREC_BF16X3 = 1 /* split-bf16, 3 MFMA per product, fp32 accumulate */
+  SRN_PREC_BF16X3 = 1, /* split-bf16 (hi + lo), 3 MFMA per product, fp32 accumulate: ~2^-17 per product */
+  SRN_PREC_BF16X6 = 2  /* fp32-faithful emulation: exact (hi + mid + lo) split, 6 MFMA per product, fp32 accumulate:
+                        * <= 2^-26 per product (below fp32's own rounding unit).  Kernels without a bf16x6 variant
+                        * (generic conv_gemm, halo / strip, srn_hifigan_resunit) run their exact-fp32 path instead. */
 };
 
 /*
@@ -105,7 +108,8 @@ typedef struct SrnConvParams {
   /* ws / ws_bytes: optional caller-owned workspace (16-byte aligned, at least srn_conv_gemm_workspace_bytes(p)
    * bytes, shared by all calls of one stream).  With it, launches whose tile grid cannot fill the chip are split
    * over K (conv_splitk.hip); without it (NULL) they run unsplit.  Results agree to fp32 summation order.
-   * w_lo: reserved, NULL.
+   * w_lo (SRN_PREC_BF16X6 only): the lo plane of the pre-split weights, bf16 [N][n_taps][roundup(C_in, 32) / 32][32];
+   *   w_hi then holds [hi 32 | mid 32].  NULL otherwise.
    * w_hi (SRN_PREC_BF16X3 only): the static weights already split at load time, bf16
    * [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32]; NULL: the kernel splits the fp32 rows of `w` per call. */
   void* ws; int64_t ws_bytes;

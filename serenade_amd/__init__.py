@@ -5,14 +5,17 @@ Contraction arithmetic policy (applies to plans built afterwards):
     serenade_amd.set_precision("bf16x3")   # default: every fp32 operand split into (hi, lo) bf16, 3 MFMA per
                                            # product, fp32 accumulate (~2^-17 relative per product)
     serenade_amd.set_precision("fp32")     # exact fp32 MFMA (bit-for-bit an fp32 fma chain)
+    serenade_amd.set_precision("bf16x6")   # fp32-faithful emulation: operands split EXACTLY into (hi, mid, lo) bf16,
+                                           # 6 MFMA per product, fp32 accumulate; dropped terms <= 2^-26 per product
+                                           # (below fp32's rounding unit) at 6/16 of the fp32-MFMA cost
 
-or the environment variable SERENADE_AMD_PRECISION=fp32|bf16x3.
+or the environment variable SERENADE_AMD_PRECISION=fp32|bf16x3|bf16x6.
 """
 import os
 
 from . import _lib, ops
 
-_NAMES = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3}
+_NAMES = {"fp32": _lib.PREC_FP32, "bf16x3": _lib.PREC_BF16X3, "bf16x6": _lib.PREC_BF16X6}
 
 
 def set_precision(name):

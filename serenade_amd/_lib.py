@@ -14,7 +14,7 @@ SRN_MAX_TAPS = 16
 ACT_NONE, ACT_LEAKY, ACT_SILU, ACT_MISH = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_AXPY = 0, 1, 2
 POST_NONE, POST_DIV, POST_TANH, POST_RELU, POST_LEAKY = 0, 1, 2, 3, 4
-PREC_FP32, PREC_BF16X3 = 0, 1
+PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
 
 
 class SrnConvParams(ctypes.Structure):

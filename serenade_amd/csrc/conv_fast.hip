@@ -46,10 +46,31 @@ __device__ __forceinline__ void split_pair(const float a, const float b, unsigne
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
 }
 
+// x = hi + mid + lo EXACTLY (three round-to-nearest bf16 of successive exact residuals: 8 + 8 + 8 significand bits
+// cover fp32's 24; x - hi and (x - hi) - mid are exact in fp32)
+__device__ __forceinline__ void split3_pair(const float a, const float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  f32x2 hf;
+  hf.x = __builtin_bit_cast(float, hi << 16);
+  hf.y = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const f32x2 r1 = v - hf;
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  f32x2 mf;
+  mf.x = __builtin_bit_cast(float, mid << 16);
+  mf.y = __builtin_bit_cast(float, mid & 0xffff0000u);
+  const f32x2 r2 = r1 - mf;
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
 // NSTAGE: LDS stages.  2: tile s+1 is split / written while tile s is multiplied.  1: the two phases alternate
 // between barriers inside a workgroup and a third co-resident workgroup (32 KB each) supplies the overlap.
 // PREC: 1 = split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per product), 0 = exact fp32 (v_mfma_f32_32x32x2_f32); the fp32
 // LDS image is [rows][32 floats + 4 pad] (144-B rows: conflict-free ds_read_b128 of 16 rows), A then B.
+// PREC 2 = bf16x6, fp32-FAITHFUL emulation: operands split exactly into (hi, mid, lo) bf16 planes, a product is the six
+// MFMAs lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi (every bf16 x bf16 product is exact in the fp32 accumulate);
+// the dropped mid*lo, lo*mid, lo*lo terms are <= 2^-26 of the product -- a quarter of fp32's own rounding unit -- at
+// 6 / 16 of the fp32-MFMA cost.  LDS: three 64-B-row planes per operand.
 template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_ = 2, int PREC_ = 1>
 struct FCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, PREC = PREC_;
@@ -57,10 +78,14 @@ struct FCfg {
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
   static constexpr int A_LD = BM / 32, B_LD = BN / 32;  // 16-B loads per thread per step
-  static constexpr int STAGE = (BM + BN) * (PREC ? 128 : 144);  // split: [A_hi | A_lo | B_hi | B_lo], 64 B per row
+  static constexpr int NPL = PREC == 2 ? 3 : 2;         // bf16 planes per operand
+  static constexpr int B_LD2 = PREC == 2 ? BN / 64 : 0;  // bf16x6: extra 16-B loads per thread for the lo weight plane
+  static_assert(PREC != 2 || BN % 64 == 0 || BN == 32, "lo-plane pieces must divide over the workgroup");
+  static constexpr int STAGE = (BM + BN) * (PREC ? 64 * NPL : 144);  // split: [A planes | B planes], 64 B per row
   static constexpr int SMEM_BYTES = NSTAGE * STAGE;
   // workgroups per CU the kernel is compiled for (register budget 512 / waves per SIMD): three where the LDS allows
-  static constexpr int MIN_BLOCKS = SMEM_BYTES * 3 <= 160 * 1024 ? 3 : 2;
+  // (two at most in bf16x6: 3 x (MT + NT) fragments + the accumulators do not fit 168 registers)
+  static constexpr int MIN_BLOCKS = SMEM_BYTES * 2 > 160 * 1024 ? 1 : (SMEM_BYTES * 3 <= 160 * 1024 && PREC != 2 ? 3 : 2);
 };
 
 // ACT: SRN_ACT_NONE / SRN_ACT_LEAKY compile-time, -1 = run-time p.pro_act (SiLU / Mish).
@@ -152,9 +177,23 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
 #pragma unroll
   for (int i = 0; i < C::B_LD; ++i) bptr[i] += (int64_t)s_begin * BK;
   int bbump = BK;  // floats per step (0 once the cursor is parked)
+  // bf16x6 with pre-split weights: the (hi | mid) planes arrive through bptr like bf16x3's (hi | lo); the lo plane is a
+  // second image [N][steps][32 bf16] (p.w_lo) whose 64-B lines are 4 pieces: thread -> (row tid / 4 + 64 j, piece tid % 4)
+  constexpr int B_LD2 = (WPL && C::PREC == 2) ? (C::B_LD2 > 0 ? C::B_LD2 : 1) : 0;
+  constexpr bool LO_ALL = C::BN >= 64;  // BN = 32: only threads 0..127 carry a piece
+  const float* cptr[B_LD2 > 0 ? B_LD2 : 1];
+  const int c_q4 = tid & 3, c_row = tid >> 2;
+  if constexpr (B_LD2 > 0) {
+#pragma unroll
+    for (int j = 0; j < B_LD2; ++j) {
+      const int n = min(n0 + min(c_row + 64 * j, C::BN - 1), p.N - 1);
+      cptr[j] = reinterpret_cast<const float*>(p.w_lo) + ((int64_t)n * steps_all + s_begin) * 16 + c_q4 * 4;
+    }
+  }
   struct Regs {
     float4 pa[C::A_LD];
     float4 pb[C::B_LD];
+    float4 pc[B_LD2 > 0 ? B_LD2 : 1];
   };
   // issue-only: nothing here consumes a loaded value
   auto load_issue = [&](Regs& R) {
@@ -167,6 +206,13 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     for (int i = 0; i < C::B_LD; ++i) {
       R.pb[i] = *reinterpret_cast<const float4*>(bptr[i]);
       bptr[i] += bbump;
+    }
+    if constexpr (B_LD2 > 0) {
+#pragma unroll
+      for (int j = 0; j < B_LD2; ++j) {
+        R.pc[j] = *reinterpret_cast<const float4*>(cptr[j]);
+        cptr[j] += bbump >> 1;  // 64-B lines
+      }
     }
   };
   auto cursor_advance = [&]() {
@@ -190,6 +236,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
         }
 #pragma unroll
         for (int i = 0; i < C::B_LD; ++i) bptr[i] -= BK;
+        if constexpr (B_LD2 > 0) {
+#pragma unroll
+          for (int j = 0; j < B_LD2; ++j) cptr[j] -= BK / 2;
+        }
         bbump = 0;
         left = 1 << 30;
       }
@@ -200,11 +250,14 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
   const float pro_slope = p.pro_slope;
   const int st_off = bf_off(lrow, c4 * 4);          // A (and fp32 B) rows: 8-B slot of this thread's float4
   const int stb_off = bf_off(lrow, (c4 & 3) * 8);   // plane B rows: 16-B slot of this thread's piece
+  constexpr int NPL = C::NPL;
+  const int stc_off = bf_off(c_row, c_q4 * 8);  // bf16x6 lo weight plane: 16-B slot of this thread's piece
   auto store = [&](const int stage, Regs& R) {
+    // planes: A [hi | (mid) | lo] then B [hi | (mid) | lo]; "lo" below is the LAST plane, "mid" exists for NPL = 3
     unsigned char* sa_hi = smem_f + stage * C::STAGE;
-    unsigned char* sa_lo = sa_hi + BM * 64;
-    unsigned char* sb_hi = sa_lo + BM * 64;
-    unsigned char* sb_lo = sb_hi + BN * 64;
+    unsigned char* sa_lo = sa_hi + (NPL - 1) * BM * 64;
+    unsigned char* sb_hi = sa_hi + NPL * BM * 64;
+    unsigned char* sb_lo = sb_hi + (NPL - 1) * BN * 64;
     if constexpr (C::PREC == 0) {
       float* a32 = reinterpret_cast<float*>(smem_f + stage * C::STAGE) + lrow * 36 + c4 * 4;
       float* b32 = a32 + BM * 36;
@@ -248,25 +301,54 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
         v.z = srn_act(v.z, pro_act, pro_slope);
         v.w = srn_act(v.w, pro_act, pro_slope);
       }
-      uint2 hi, lo;
-      split_pair(v.x, v.y, hi.x, lo.x);
-      split_pair(v.z, v.w, hi.y, lo.y);
-      *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
-      *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
+      if constexpr (NPL == 3) {
+        uint2 hi, mid, lo;
+        split3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+        split3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+        *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
+        *reinterpret_cast<uint2*>(sa_hi + BM * 64 + st_off + i * 2048) = mid;
+        *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
+      } else {
+        uint2 hi, lo;
+        split_pair(v.x, v.y, hi.x, lo.x);
+        split_pair(v.z, v.w, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(sa_hi + st_off + i * 2048) = hi;
+        *reinterpret_cast<uint2*>(sa_lo + st_off + i * 2048) = lo;
+      }
     }
     if constexpr (WPL) {
-      unsigned char* dst = (c4 < 4 ? sb_hi : sb_lo) + stb_off;
+      // (hi | lo) of bf16x3, (hi | mid) of bf16x6: 128-B lines, pieces 0-3 -> first plane, 4-7 -> second
+      unsigned char* dst = (c4 < 4 ? sb_hi : sb_hi + BN * 64) + stb_off;
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) *reinterpret_cast<float4*>(dst + i * 2048) = R.pb[i];
+      if constexpr (B_LD2 > 0) {
+        if (LO_ALL || c_row < C::BN) {
+#pragma unroll
+          for (int j = 0; j < B_LD2; ++j) {
+            float4 v = R.pc[j];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            *reinterpret_cast<float4*>(sb_lo + stc_off + j * 4096) = v;
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < C::B_LD; ++i) {
         const float4 v = R.pb[i];
-        uint2 hi, lo;
-        split_pair(v.x, v.y, hi.x, lo.x);
-        split_pair(v.z, v.w, hi.y, lo.y);
-        *reinterpret_cast<uint2*>(sb_hi + st_off + i * 2048) = hi;
-        *reinterpret_cast<uint2*>(sb_lo + st_off + i * 2048) = lo;
+        if constexpr (NPL == 3) {
+          uint2 hi, mid, lo;
+          split3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+          split3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+          *reinterpret_cast<uint2*>(sb_hi + st_off + i * 2048) = hi;
+          *reinterpret_cast<uint2*>(sb_hi + BN * 64 + st_off + i * 2048) = mid;
+          *reinterpret_cast<uint2*>(sb_lo + st_off + i * 2048) = lo;
+        } else {
+          uint2 hi, lo;
+          split_pair(v.x, v.y, hi.x, lo.x);
+          split_pair(v.z, v.w, hi.y, lo.y);
+          *reinterpret_cast<uint2*>(sb_hi + st_off + i * 2048) = hi;
+          *reinterpret_cast<uint2*>(sb_lo + st_off + i * 2048) = lo;
+        }
       }
     }
   };
@@ -289,9 +371,9 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
 
   auto compute = [&](const int stage) {
     const unsigned char* sa_hi = smem_f + stage * C::STAGE;
-    const unsigned char* sa_lo = sa_hi + BM * 64;
-    const unsigned char* sb_hi = sa_lo + BM * 64;
-    const unsigned char* sb_lo = sb_hi + BN * 64;
+    const unsigned char* sa_lo = sa_hi + (NPL - 1) * BM * 64;
+    const unsigned char* sb_hi = sa_hi + NPL * BM * 64;
+    const unsigned char* sb_lo = sb_hi + (NPL - 1) * BN * 64;
     if constexpr (C::PREC == 0) {
       const float* a = reinterpret_cast<const float*>(smem_f + stage * C::STAGE) + (wm0 + li) * 36 + 4 * lh;
       const float* b = reinterpret_cast<const float*>(smem_f + stage * C::STAGE) + (BM + wn0 + li) * 36 + 4 * lh;
@@ -335,21 +417,28 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
         bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + fr_b + n * 2048 + choff);
         bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + fr_b + n * 2048 + choff);
       }
+#define SRN_MFMA_GROUP(A_, B_)                                                                   \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n) \
+      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[m], B_[n], acc[m][n], 0, 0, 0);
+      if constexpr (NPL == 3) {
+        bf16x8 am[MT], bm[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) am[m] = *reinterpret_cast<const bf16x8*>(sa_hi + BM * 64 + fr_a + m * 2048 + choff);
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) bm[n] = *reinterpret_cast<const bf16x8*>(sb_hi + BN * 64 + fr_b + n * 2048 + choff);
+        // smallest terms first: 2^-16 (lo*hi, hi*lo, mid*mid), 2^-8 (mid*hi, hi*mid), 1 (hi*hi)
+        SRN_MFMA_GROUP(al, bh)
+        SRN_MFMA_GROUP(ah, bl)
+        SRN_MFMA_GROUP(am, bm)
+        SRN_MFMA_GROUP(am, bh)
+        SRN_MFMA_GROUP(ah, bm)
+        SRN_MFMA_GROUP(ah, bh)
+      } else {
+        SRN_MFMA_GROUP(al, bh)
+        SRN_MFMA_GROUP(ah, bl)
+        SRN_MFMA_GROUP(ah, bh)
+      }
+#undef SRN_MFMA_GROUP
     }
   };
 
@@ -362,18 +451,20 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     store(ss, Rs);
     load_issue(Rl);
     constexpr bool F32 = C::PREC == 0;
-    constexpr int N_MFMA = MT * NT * (F32 ? 16 : 6);
-    constexpr int N_DSR = (MT + NT) * 4;
-    constexpr int N_LD = C::A_LD + C::B_LD;
+    constexpr int N_MFMA = MT * NT * (F32 ? 16 : 3 * (NPL - 1));
+    constexpr int N_DSR = F32 ? (MT + NT) * 4 : (MT + NT) * 2 * NPL;
+    constexpr int N_LD = C::A_LD + C::B_LD + B_LD2;
+    constexpr int SPL = NPL == 3 ? 16 : 10;  // VALU of one float4 split
     constexpr int N_VALU = F32 ? C::A_LD * (ACT == SRN_ACT_NONE ? 0 : 8) + N_LD
-                               : C::A_LD * (ACT == SRN_ACT_NONE ? 10 : 18) + (WPL ? 0 : C::B_LD * 10) + N_LD;
-    constexpr int N_DSW = F32 ? C::A_LD + C::B_LD : C::A_LD * 2 + (WPL ? C::B_LD : C::B_LD * 2);
+                               : C::A_LD * (SPL + (ACT == SRN_ACT_NONE ? 0 : 8)) + (WPL ? 0 : C::B_LD * SPL) + N_LD;
+    constexpr int N_DSW = F32 ? C::A_LD + C::B_LD : C::A_LD * NPL + (WPL ? C::B_LD + B_LD2 : C::B_LD * NPL);
     constexpr int VPM = (N_VALU + N_MFMA - 1) / N_MFMA;
-    __builtin_amdgcn_sched_group_barrier(0x100, F32 ? (MT + NT) : (MT + NT) * 2, 0);  // fragments of the first k slice
+    constexpr int DSR0 = F32 ? (MT + NT) : (MT + NT) * NPL;
+    __builtin_amdgcn_sched_group_barrier(0x100, DSR0, 0);  // fragments of the first k slice
 #pragma unroll
     for (int i = 0; i < N_MFMA; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < N_DSR - (F32 ? (MT + NT) : (MT + NT) * 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < N_DSR - DSR0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       if (i * N_LD / N_MFMA != (i + 1) * N_LD / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
       if (i * N_DSW / N_MFMA != (i + 1) * N_DSW / N_MFMA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -465,14 +556,16 @@ int launch_fast(const SrnConvParams& p, bool wpl, hipStream_t stream, int ks = 1
 int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit) {
   if (p.w_nmajor) return 0;
   if (p.C_in % BK != 0 || p.C_in0 % BK != 0) return 0;
-  const bool f32 = p.precision != SRN_PREC_BF16X3;
-  const bool wpl = !f32 && p.w_hi != nullptr && p.w_bs == 0 && p.w_hs == 0;
+  const bool x6 = p.precision == SRN_PREC_BF16X6;
+  const bool f32 = p.precision != SRN_PREC_BF16X3 && !x6;
+  const bool wpl = !f32 && p.w_hi != nullptr && (!x6 || p.w_lo != nullptr) && p.w_bs == 0 && p.w_hs == 0;
   if (!wpl) {
     // fp32 B rows walked contiguously over (tap, channel): needs the packed [tap][C_in] row layout, all of it live
     if (p.C_w != p.C_in || p.ldw < p.n_taps * p.C_in) return 0;
   }
   if (ksplit > 1) {  // split-K launches always take the 64 x 64 tile (they exist because the grid is small)
     if (f32) return launch_fast<FCfg<64, 64, 32, 32, 2, 0>>(p, false, stream, ksplit);
+    if (x6) return launch_fast<FCfg<64, 64, 32, 32, 2, 2>>(p, wpl, stream, ksplit);
     return launch_fast<FCfg<64, 64, 32, 32>>(p, wpl, stream, ksplit);
   }
   if (f32) {
@@ -482,6 +575,16 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int 
       case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 0>>(p, false, stream);
       case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 0>>(p, false, stream);
       case 5: return launch_fast<FCfg<128, 32, 32, 32, 2, 0>>(p, false, stream);
+      default: return 0;
+    }
+  }
+  if (x6) {
+    switch (tile) {
+      case 1: return launch_fast<FCfg<128, 128, 64, 64, 1, 2>>(p, wpl, stream);  // one LDS stage (48 KB), 2 / CU
+      case 2: return launch_fast<FCfg<128, 64, 32, 64, 2, 2>>(p, wpl, stream);
+      case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 2>>(p, wpl, stream);
+      case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 2>>(p, wpl, stream);
+      case 5: return launch_fast<FCfg<128, 32, 32, 32, 2, 2>>(p, wpl, stream);
       default: return 0;
     }
   }

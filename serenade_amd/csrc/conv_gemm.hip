@@ -406,14 +406,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
 
 struct TileInfo {
   int id, bm, bn, wn;
-  float base[2];  // measured relative efficiency of the tile shape on large grids: [fp32, split-bf16]
+  float base[3];  // measured relative efficiency of the tile shape on large grids: [fp32, split-bf16, bf16x6]
 };
 // id: 1 128x128 (64x64/wave) | 2 128x64 (32x64) | 3 64x128 (32x64) | 4 64x64 (32x32) | 5 128x32 (32x32)
 // (priors from tools/opbench.py --sweep on MI355X: in fp32 the MFMA phase is long and the small tile loses nothing;
 //  in split-bf16 the kernel is L2-traffic sensitive and bigger tiles win)
-const TileInfo kTiles[] = {{1, 128, 128, 64, {1.00f, 1.00f}}, {2, 128, 64, 64, {0.90f, 0.95f}},
-                           {3, 64, 128, 64, {0.92f, 0.97f}},  {4, 64, 64, 32, {0.97f, 0.85f}},
-                           {5, 128, 32, 32, {0.85f, 0.75f}}};
+const TileInfo kTiles[] = {{1, 128, 128, 64, {1.00f, 1.00f, 1.00f}}, {2, 128, 64, 64, {0.90f, 0.95f, 0.95f}},
+                           {3, 64, 128, 64, {0.92f, 0.97f, 0.97f}},  {4, 64, 64, 32, {0.97f, 0.85f, 0.90f}},
+                           {5, 128, 32, 32, {0.85f, 0.75f, 0.80f}}};
 
 template <class C, int ACT, int PREC>
 int launch_prec(const SrnConvParams& p, hipStream_t stream) {
@@ -458,7 +458,7 @@ int pick_tile(const SrnConvParams& p) {
     double quant = blocks / (256.0 * (double)(int64_t)rounds);
     // fewer blocks than CUs idles CUs outright; beyond one round, co-resident blocks absorb part of the tail
     if (blocks > 256.0) quant = 0.35 + 0.65 * quant;
-    float score = (float)(useful * quant) * t.base[p.precision == SRN_PREC_BF16X3 ? 1 : 0];
+    float score = (float)(useful * quant) * t.base[p.precision == SRN_PREC_BF16X3 ? 1 : (p.precision == SRN_PREC_BF16X6 ? 2 : 0)];
     // both operands split in the loop (Q K^T, P V): the 64x128 tile measured 5-10 % ahead of 128x128
     if (p.precision == SRN_PREC_BF16X3 && (p.w_hi == nullptr || p.w_bs != 0 || p.w_hs != 0) && t.id == 1)
       score *= 0.92f;

@@ -15,6 +15,8 @@
 
 namespace {
 
+constexpr int MAX_KSPLIT = 8;
+
 // one workgroup per (z, 32-row, 32-column) block: thread -> (row tid / 8, 4 columns at 4 (tid % 8)); the block is
 // exactly one GroupNorm partial-sum tile
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SrnConvParams p, const int ksplit, const int m32,
@@ -35,10 +37,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SrnConvParams 
   const int64_t slab = Z * p.T_out * p.N;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
+    // all (up to MAX_KSPLIT) slices' loads are issued back to back from clamped addresses and summed in slice order:
+    // a run-time-length load loop pays one dependent memory round trip per slice (measured 5.9 us per call at B = 1)
     const float* w = reinterpret_cast<const float*>(p.ws) + ((int64_t)z * p.T_out + row) * p.N + col;
-    for (int s = 0; s < ksplit; ++s) {
-      const float4 q = *reinterpret_cast<const float4*>(w + s * slab);
-      v[0] += q.x, v[1] += q.y, v[2] += q.z, v[3] += q.w;
+    float4 q[MAX_KSPLIT];
+#pragma unroll
+    for (int s = 0; s < MAX_KSPLIT; ++s) q[s] = *reinterpret_cast<const float4*>(w + min(s, ksplit - 1) * slab);
+#pragma unroll
+    for (int s = 0; s < MAX_KSPLIT; ++s) {
+      const float on = s < ksplit ? 1.f : 0.f;
+      v[0] += on * q[s].x, v[1] += on * q[s].y, v[2] += on * q[s].z, v[3] += on * q[s].w;
     }
   }
   int len_out = p.T_out;
@@ -94,15 +102,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SrnConvParams 
 int srn_splitk_plan(const SrnConvParams& p) {
   if (p.geglu || p.out_tr != nullptr || p.w_nmajor || p.N % 4 != 0) return 1;
   if (p.C_in % 32 != 0 || p.C_in0 % 32 != 0) return 1;
-  const bool wpl = p.precision == SRN_PREC_BF16X3 && p.w_hi != nullptr && p.w_bs == 0 && p.w_hs == 0;
+  const bool wpl = ((p.precision == SRN_PREC_BF16X3 && p.w_hi != nullptr) ||
+                    (p.precision == SRN_PREC_BF16X6 && p.w_hi != nullptr && p.w_lo != nullptr)) &&
+                   p.w_bs == 0 && p.w_hs == 0;
   if (!wpl && (p.C_w != p.C_in || p.ldw < p.n_taps * p.C_in)) return 1;
   if (p.gn_partials && p.n_head != 1) return 1;
   const int steps = p.n_taps * (p.C_in / 32);
-  if (steps < 12) return 1;
+  // measured at B = 1 (1 workgroup per CU): ~4 us launch ramp + ~0.5 us per dependent k-step unsplit, vs ramp +
+  // steps / ks + a ~3 us reduce launch when split -- below ~24 steps the reduce eats the gain
+  if (steps < 24) return 1;
   const int64_t tiles = (int64_t)p.n_batch * p.n_head * ((p.T_out + 63) / 64) * ((p.N + 63) / 64);
   if (tiles > 192) return 1;
   int ks = (int)(448 / tiles);  // ~1.75 workgroups per CU
-  ks = ks > 8 ? 8 : ks;
+  ks = ks > MAX_KSPLIT ? MAX_KSPLIT : ks;
   ks = ks > steps / 4 ? steps / 4 : ks;  // at least four steps per slice
   if (ks < 2) return 1;
   const int per = (steps + ks - 1) / ks;

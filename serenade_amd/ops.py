@@ -86,12 +86,14 @@ class ConvOp:
         self.p = p
         self._fn = _lib.lib().srn_conv_gemm
         self._wplanes = None
-        if p.precision == _lib.PREC_BF16X3:
-            # static weights are split once, at plan-build time, into the bf16 hi|lo plane image conv_fast.hip streams
-            # straight into LDS
+        if p.precision in (_lib.PREC_BF16X3, _lib.PREC_BF16X6):
+            # static weights are split once, at plan-build time, into the bf16 plane images conv_fast.hip streams
+            # straight into LDS: (hi | lo) for bf16x3; (hi | mid) + a separate lo plane for bf16x6
             if isinstance(w, torch.Tensor) and w.is_cuda and p.w_bs == 0 and p.w_hs == 0 and not w_nmajor:
-                self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw)
+                self._wplanes = weight_planes(w, p.N, p.n_taps, p.C_in, p.ldw, three=p.precision == _lib.PREC_BF16X6)
                 p.w_hi = self._wplanes[0].data_ptr()
+                if p.precision == _lib.PREC_BF16X6:
+                    p.w_lo = self._wplanes[2].data_ptr()
         if SPLITK and isinstance(out, (torch.Tensor, tuple)):
             o = out[0] if isinstance(out, tuple) else out
             if o.is_cuda and self._fn and _lib.lib().srn_conv_gemm_workspace_bytes(ctypes.byref(p)) > 0:
@@ -171,16 +173,18 @@ def drop_weight_planes(tensors):
         del _WPLANES[key]
 
 
-def weight_planes(w, N, n_taps, C_in, ldw):
+def weight_planes(w, N, n_taps, C_in, ldw, three=False):
     """fp32 packed weights [N][n_taps * C_in] -> bf16 planes [N][n_taps][roundup(C_in, 32) / 32][hi 32 | lo 32],
     hi = bf16(w), lo = bf16(w - hi) (round-to-nearest-even, the same split the kernels apply to activations).
+    three=True (bf16x6): the exact three-way split w = hi + mid + lo; returns (planes [..][hi 32 | mid 32], w,
+    lo plane [N][n_taps][chunks][32]).
     The cache key carries the tensor's in-place version counter: `load_state_dict` copies into the live parameter
     (same address, version + 1), which therefore misses the cache and is split again."""
     try:
         version = w._version
     except RuntimeError:  # tensors created under torch.inference_mode() carry no counter (and cannot be written)
         version = -1
-    key = (w.data_ptr(), version, tuple(w.shape), N, n_taps, C_in, ldw)
+    key = (w.data_ptr(), version, tuple(w.shape), N, n_taps, C_in, ldw, bool(three))
     if key not in _WPLANES:
         for stale in [k for k in _WPLANES if k[0] == key[0] and k[2:] == key[2:]]:
             del _WPLANES[stale]  # an older value of the same tensor
@@ -189,10 +193,15 @@ def weight_planes(w, N, n_taps, C_in, ldw):
         full = torch.zeros(N, n_taps, cp, device=w.device, dtype=torch.float32)
         full[:, :, :C_in] = src
         hi = full.to(torch.bfloat16)
-        lo = (full - hi.to(torch.float32)).to(torch.bfloat16)
+        r1 = full - hi.to(torch.float32)
+        lo = r1.to(torch.bfloat16)  # bf16x3: second plane; bf16x6: the MID plane
         # kernel layout: per row, per 32-channel chunk, [32 hi | 32 lo]  (one 128-B line per chunk)
         pl = torch.stack([hi.view(N, n_taps, cp // 32, 32), lo.view(N, n_taps, cp // 32, 32)], dim=3).contiguous()
-        _WPLANES[key] = (pl, w)  # keep `w` alive so the data_ptr key stays unique
+        if three:
+            third = (r1 - lo.to(torch.float32)).to(torch.bfloat16).view(N, n_taps, cp // 32, 32).contiguous()
+            _WPLANES[key] = (pl, w, third)
+        else:
+            _WPLANES[key] = (pl, w)  # keep `w` alive so the data_ptr key stays unique
     return _WPLANES[key]
 
 

@@ -33,7 +33,7 @@ MEL_RTOL, WAVE_ATOL = 1e-3, 1e-4
 _ORACLE = {}
 
 
-@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3", "bf16x6"])
 def precision(request):
     serenade_amd.set_precision(request.param)
     yield request.param

@@ -13,10 +13,10 @@ from tests.test_hip_parity import KTOL, dev, rnd, run_conv_both  # noqa: F401  (
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3", "bf16x6"])
 def precision(request):
     serenade_amd.set_precision(request.param)
-    KTOL.k = 2e-5 if request.param == "fp32" else 1e-4
+    KTOL.k = 1e-4 if request.param == "bf16x3" else 2e-5
     yield request.param
     serenade_amd.set_precision("bf16x3")
 

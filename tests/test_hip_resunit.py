@@ -20,7 +20,7 @@ from tests import _emulator
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3", "bf16x6"])
 def precision(request):
     serenade_amd.set_precision(request.param)
     yield request.param
@@ -35,7 +35,7 @@ def dev():
 
 
 def tol():
-    return 2e-5 if serenade_amd.get_precision() == "fp32" else 1e-4
+    return 1e-4 if serenade_amd.get_precision() == "bf16x3" else 2e-5
 
 
 def nerr(a, b):
@@ -124,7 +124,7 @@ class Mirror:
 
 @pytest.mark.parametrize("case", ["plain_gn", "residual_inplace", "axpy_masked", "strided_leaky_concat"])
 def test_splitk_path_matches_spec(dev, case):
-    B, T, K, N = 1, 150, 128, 160  # 3 x 3 tiles of 64 x 64: the grid cannot fill the chip; 3 taps x 4 chunks
+    B, T, K, N = 1, 150, 256, 160  # 3 x 3 tiles of 64 x 64: the grid cannot fill the chip; 3 taps x 8 chunks
     taps = [-1, 0, 1]
     kw = dict(in0=rnd(B, T, K, seed=1), w=rnd(N, 3 * K, seed=2, scale=0.05), bias=rnd(N, seed=3), n_batch=B, T_in=T,
               T_out=T, C_in=K, N=N, in0_bs=T * K, ld_in0=K, ldw=3 * K, out_bs=T * N, ld_out=N, taps=taps,
@@ -140,7 +140,7 @@ def test_splitk_path_matches_spec(dev, case):
         kw.update(out=o, res=o, res_mode=ops.RES_AXPY, beta=0.1, res_bs=T * N, ld_res=N,
                   len_out=torch.tensor([101], dtype=torch.int32), len_in=torch.tensor([120], dtype=torch.int32))
     else:
-        K0 = 64
+        K0 = 96
         kw.update(in0=rnd(B, T, K0, seed=7), in1=rnd(B, T, K - K0, seed=8), C_in0=K0, in0_bs=T * K0, ld_in0=K0,
                   in1_bs=T * (K - K0), ld_in1=K - K0, pro_act=ops.ACT_LEAKY, pro_slope=0.2,
                   out=torch.zeros(B, 2 * T, N), out_bs=2 * T * N, out_t_stride=2, out_t_off=1)
@@ -155,3 +155,41 @@ def test_splitk_path_matches_spec(dev, case):
     for c, g_ in m.map.values():
         if c.is_floating_point():
             assert nerr(g_, c) < tol(), case
+
+
+# ------------------------------------------------------------------------------------------------------------------
+#  bf16x6: the fp32-faithful emulation must be AT LEAST as accurate as the exact-fp32 MFMA mode
+# ------------------------------------------------------------------------------------------------------------------
+def test_three_way_split_is_exact_on_the_host():
+    """x = hi + mid + lo exactly, for fp32 values over 60 binades (the split ops.weight_planes and the kernels apply)"""
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy((rng.standard_normal(200000) * np.exp2(rng.integers(-30, 30, 200000))).astype(np.float32))
+    hi = x.to(torch.bfloat16)
+    r1 = x - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    assert torch.equal(hi.float() + mid.float() + lo.float(), x)  # (hi + mid) + lo re-rounds to x: sums are exact
+    assert torch.equal(hi.double() + mid.double() + lo.double(), x.double())
+
+
+def test_bf16x6_gemm_error_is_not_above_exact_fp32(dev, precision):
+    """max and rms error of a K = 2048 contraction against fp64, per mode: bf16x6 must not exceed the exact-fp32 MFMA
+    path's error by more than summation-order noise (it keeps 24-bit operands and drops only <= 2^-26 of a product)"""
+    if precision != "fp32":
+        pytest.skip("one arm runs all three modes")
+    M, N, K = 384, 256, 2048
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / np.sqrt(K)), rnd(N, seed=3)
+    ref = a.double() @ w.double().t() + b.double()
+    errs = {}
+    for mode in ("fp32", "bf16x6", "bf16x3"):
+        serenade_amd.set_precision(mode)
+        out = torch.zeros(M, N, device=dev)
+        ops.ConvOp(in0=a.to(dev), w=w.to(dev), out=out, bias=b.to(dev), n_batch=1, T_in=M, T_out=M, C_in=K, N=N,
+                   ld_in0=K, ldw=K, ld_out=N)()
+        torch.cuda.synchronize()
+        d = (out.cpu().double() - ref)
+        errs[mode] = (d.abs().max().item(), d.pow(2).mean().sqrt().item())
+    serenade_amd.set_precision("fp32")
+    print("GEMM error vs fp64 (max, rms):", errs)
+    assert errs["bf16x6"][0] <= 1.5 * errs["fp32"][0] and errs["bf16x6"][1] <= 1.25 * errs["fp32"][1]
+    assert errs["bf16x3"][1] > 4 * errs["fp32"][1]  # the two-plane split is visibly coarser: this test can tell

@@ -88,7 +88,7 @@ def main():
     if "--no-halo" in sys.argv:
         ops.NO_HALO = True
     import serenade_amd
-    serenade_amd.set_precision("fp32" if "--fp32" in sys.argv else "bf16x3")
+    serenade_amd.set_precision("fp32" if "--fp32" in sys.argv else ("bf16x6" if "--bf16x6" in sys.argv else "bf16x3"))
     dev = torch.device("cuda:0")
     model, voc, sd, gsd = bench.build_models(dev)
     B, T, Tr = (int(os.environ.get(k, d)) for k, d in (("SRN_B", bench.B_PER_GPU), ("SRN_T", bench.T_SRC), ("SRN_TREF", bench.T_REF)))

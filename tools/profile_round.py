@@ -81,7 +81,7 @@ def counters(outdir):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     tag = args[0] if args else "r2"
-    modes = "fp32,bf16x3"
+    modes = "fp32,bf16x6,bf16x3"
     for a in sys.argv[1:]:
         if a.startswith("--modes="):
             modes = a.split("=", 1)[1]
@@ -137,13 +137,16 @@ def main():
                 f.write(f"# totals: SQ_WAIT_ANY / SQ_WAVE_CYCLES = {tot['SQ_WAIT_ANY'] / wc:.3f}; "
                         f"SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {tot['SQ_WAIT_INST_ANY'] / wc:.3f}; "
                         f"SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {tot['SQ_ACTIVE_INST_ANY'] / wc:.3f}; "
-                        f"MFMA busy / (4 * SQ_BUSY_CYCLES) = "
-                        f"{tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(4.0 * tot['SQ_BUSY_CYCLES'], 1.0):.3f}\n")
-                f.write("kernel | grid | n | " + " | ".join(SQ) + "\n")
+                        f"MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 * SQ_BUSY_CYCLES) = "
+                        f"{tot['SQ_VALU_MFMA_BUSY_CYCLES'] / max(32.0 * tot['SQ_BUSY_CYCLES'], 1.0):.3f}"
+                        f"  [busy cycles summed over 1024 SIMDs / dispatch cycles summed over 32 shader engines]\n")
+                f.write("kernel | grid | n | " + " | ".join(SQ) + " | mfma_busy_frac | wait_any_frac\n")
                 for key, v in sorted(per.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
                     cnt = max(len(x) for x in v.values())
-                    f.write(f"{key[0]:70s} {key[1]:>9s} {cnt:4d} " +
-                            " ".join(f"{sum(v[c]) / max(len(v[c]), 1):12.4g}" for c in SQ) + "\n")
+                    av = {c: sum(v[c]) / max(len(v[c]), 1) for c in SQ}
+                    f.write(f"{key[0]:70s} {key[1]:>9s} {cnt:4d} " + " ".join(f"{av[c]:12.4g}" for c in SQ) +
+                            f" {av['SQ_VALU_MFMA_BUSY_CYCLES'] / max(32.0 * av['SQ_BUSY_CYCLES'], 1.0):8.3f}"
+                            f" {av['SQ_WAIT_ANY'] / max(av['SQ_WAVE_CYCLES'], 1.0):8.3f}\n")
     json.dump(record, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     print("wrote", os.path.join(prof, f"{tag}_pmc_traffic.json"))
 
