@@ -580,7 +580,8 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int 
   }
   if (x6) {
     switch (tile) {
-      case 1: return launch_fast<FCfg<128, 128, 64, 64, 1, 2>>(p, wpl, stream);  // one LDS stage (48 KB), 2 / CU
+      // one LDS stage (48 KB, three workgroups per CU); the two-stage form (96 KB, one per CU) measured 0-40 % slower
+      case 1: return launch_fast<FCfg<128, 128, 64, 64, 1, 2>>(p, wpl, stream);
       case 2: return launch_fast<FCfg<128, 64, 32, 64, 2, 2>>(p, wpl, stream);
       case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 2>>(p, wpl, stream);
       case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 2>>(p, wpl, stream);

@@ -16,6 +16,8 @@ from serenade_amd import ops  # noqa: E402
 
 
 def sig(k):
+    if "dilation" in k:  # fused HiFi-GAN residual unit: two convs of K = k * C
+        return (k["n_batch"], k["T"], k["C"], 2 * k["k"] * k["C"], k["k"], False, False, k["dilation"], False, -2)
     return (k["n_batch"] * k.get("n_head", 1), k["T_out"], k["N"], len(k.get("taps", (0,))) * k["C_in"],
             len(k.get("taps", (0,))), bool(k.get("w_nmajor", False)), bool(k.get("geglu", False)),
             k.get("in_stride", 1), bool(k.get("gn_partials") is not None), k.get("pro_act", 0))
@@ -24,7 +26,7 @@ def sig(k):
 def time_ops(oplist, reps=20):
     agg = collections.OrderedDict()
     for op in oplist:
-        if not isinstance(op, ops.ConvOp):
+        if not isinstance(op, (ops.ConvOp, ops.ResUnitOp)):
             continue
         op()
         torch.cuda.synchronize()
