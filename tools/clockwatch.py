@@ -17,17 +17,26 @@ def main():
     M, N, K = (int(os.environ.get(k, d)) for k, d in (("SRN_M", 10240), ("SRN_N", 2048), ("SRN_K", 2048)))
     x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
     out = torch.empty(M, N, device=dev)
-    prec = _lib.PREC_FP32 if "--fp32" in sys.argv else _lib.PREC_BF16X3
+    prec = (_lib.PREC_FP32 if "--fp32" in sys.argv else
+            (_lib.PREC_BF16X6 if "--bf16x6" in sys.argv else _lib.PREC_BF16X3))
     op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
                     precision=prec, tile=int(os.environ.get("SRN_TILE", "1")))
     stop = False
+    seen = {"sclk": [], "power": []}
 
     def watch():
+        import re
         while not stop:
             r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True)
             for ln in r.stdout.splitlines():
                 if "sclk" in ln or "Power" in ln or "mclk" in ln:
                     print(ln.strip(), flush=True)
+                m = re.search(r"sclk clock level.*\((\d+)Mhz\)", ln)
+                if m:
+                    seen["sclk"].append(int(m.group(1)))
+                m = re.search(r"Power \(W\): ([0-9.]+)", ln)
+                if m:
+                    seen["power"].append(float(m.group(1)))
             time.sleep(0.5)
 
     th = threading.Thread(target=watch)
@@ -42,7 +51,12 @@ def main():
     el = time.time() - t0
     stop = True
     th.join()
-    print(f"{n} launches in {el:.2f} s -> {el / n * 1e6:.1f} us each, {2.0 * M * N * K * n / el / 1e12:.1f} TF/s")
+    import statistics
+    med = lambda v: statistics.median(v[1:]) if len(v) > 1 else (v[0] if v else float("nan"))
+    name = {_lib.PREC_FP32: "fp32", _lib.PREC_BF16X3: "bf16x3", _lib.PREC_BF16X6: "bf16x6"}[prec]
+    print(f"SUMMARY {name} {M}x{N}x{K}: {n} launches in {el:.2f} s -> {el / n * 1e6:.1f} us each, "
+          f"{2.0 * M * N * K * n / el / 1e12:.1f} TF/s; median sclk {med(seen['sclk'])} MHz, median power "
+          f"{med(seen['power'])} W")
 
 
 if __name__ == "__main__":
