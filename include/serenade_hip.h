@@ -175,11 +175,6 @@ int srn_transpose_ct(const float* src, float* dst, int B, int R, int Cc, int64_t
 int srn_renorm(const float* x, const float* trg_scale, const float* trg_mean, const float* voc_mean,
                const float* voc_scale, float* y, int64_t rows, int C, void* stream);
 
-/* out = (((a + b) + c) + d) / div over n floats (c, d optional): `cs += blocks[j](c)` in block order then
- * `c = cs / num_blocks` (hifigan.py:183-186) when the residual blocks of a stage ran as parallel chains. */
-int srn_stage_mean(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n, float div,
-                   void* stream);
-
 /* HiFi-GAN output stage: LeakyReLU(slope) -> Conv1d(C -> 1, k, pad (k-1)/2) -> tanh  (hifigan.py:137-149).
  * x (B, T, C) channels-last, w (k, C), y (B, T). */
 int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int k,
@@ -192,8 +187,7 @@ int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* 
  * intermediate `xt` never leaves LDS, weights stream through a double-buffered LDS stage -- one HBM read and one
  * write per unit instead of five passes.  Optionally the stage bookkeeping of HiFiGANGenerator.forward
  * (hifigan.py:183-186) rides in the epilogue:  y = (y + res2) / post_div.
- *   x, out, res2: (n_batch, T, C) channels-last fp32, rows contiguous (ld = C); out must not alias x (res2 may be
- *   out: in-place running sum).
+ *   x, out, res2: (n_batch, T, C) channels-last fp32, rows contiguous (ld = C); out must not alias x.
  *   w1, w2: packed [C][k * C] fp32 (tap-major, as srn_conv_gemm's k-major weights); b1, b2: (C).
  *   w1_hi, w2_hi: SRN_PREC_BF16X3 only -- the same weights as bf16 planes [C][k][C / 32][hi 32 | lo 32].
  */

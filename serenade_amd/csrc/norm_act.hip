@@ -367,28 +367,6 @@ __global__ __launch_bounds__(256) void out_conv_tanh_kernel(const float* __restr
   y[(int64_t)b * T + t] = tanhf(acc);
 }
 
-// out = (((a + b) + c) + d) / div over n floats (n % 4 == 0), c / d optional: the mean over HiFi-GAN's parallel
-// residual blocks (hifigan.py:183-186: cs += block(c) in block order, then / num_blocks) when the blocks ran as
-// independent chains on side streams
-__global__ __launch_bounds__(256) void stage_mean_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                         const float4* __restrict__ c, const float4* __restrict__ d,
-                                                         float4* __restrict__ out, const int64_t n4, const float div) {
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += gridDim.x * 256ll) {
-    float4 v = a[i];
-    const float4 w = b[i];
-    v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
-    if (c) {
-      const float4 u = c[i];
-      v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
-    }
-    if (d) {
-      const float4 u = d[i];
-      v.x += u.x, v.y += u.y, v.z += u.z, v.w += u.w;
-    }
-    out[i] = make_float4(v.x / div, v.y / div, v.z / div, v.w / div);
-  }
-}
-
 // generic (any C % 4 == 0, k <= 16) fallback of the above
 __global__ __launch_bounds__(256) void out_conv_tanh_generic(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
@@ -511,22 +489,6 @@ extern "C" int srn_renorm(const float* x, const float* trg_scale, const float* t
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(renorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, trg_scale, trg_mean,
                      voc_mean, voc_scale, y, rows * C, C);
-  SRN_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int srn_stage_mean(const float* a, const float* b, const float* c, const float* d, float* out, int64_t n,
-                              float div, void* stream) {
-  SRN_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0 && div != 0.f && (c || !d), "stage_mean: bad args");
-  SRN_CHECK_ARG(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
-                  reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
-                "stage_mean: 16-byte aligned tensors");
-  int64_t blocks = (n / 4 + 255) / 256;
-  blocks = blocks > 4096 ? 4096 : blocks;
-  hipLaunchKernelGGL(stage_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
-                     reinterpret_cast<const float4*>(c), reinterpret_cast<const float4*>(d),
-                     reinterpret_cast<float4*>(out), n / 4, div);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -331,7 +331,6 @@ class DecoderPlan:
         pre.append(lin(self.spk, B, dec.spk_embed_dim, P["spk_w"], P["spk_b"], self.ss, self.ss.shape[1]))
         self.pre = pre
 
-        small = ops.PARALLEL and B * L <= ops.PARALLEL_MAX_ROWS
         tb_ld = self.tb.shape[1]
         ss_ld = self.ss.shape[1]
         tb_off, ss_off = [], []
@@ -355,19 +354,12 @@ class DecoderPlan:
             if xin1 is not None:
                 extra = dict(in1=xin1, C_in0=cin0, in1_bs=T * (cin - cin0), ld_in1=cin - cin0)
             t3 = ops.conv_taps(3)
-            chain = [conv(xin, cin, T, r["c1_w"], r["c1_b"], bufC, C, T, t3, ld_in=ld_in, len_in=ln,
-                          gn_partials=gnp, **extra),
-                     ops.gn_mish_apply_op(bufC, gnp, r["g1_w"], r["g1_b"], (self.tb, k * tb_ld + tb_off[bi]), ln,
-                                          bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0),
-                     conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp)]
-            # the 1 x 1 shortcut reads the same input and meets the chain only in the tail: at small batch x length
-            # (launches that cannot fill the chip) it runs beside the chain on a side stream
-            with ops.workspace_slot(1 if small else 0):
-                shortcut = [conv(xin, cin, T, r["r_w"], r["r_b"], bufR, C, T, [0], ld_in=ld_in, len_in=ln, **extra)]
-            if small:
-                ol.append(ops.Parallel([chain, shortcut], dev))
-            else:
-                ol += chain + shortcut
+            ol.append(conv(xin, cin, T, r["c1_w"], r["c1_b"], bufC, C, T, t3, ld_in=ld_in, len_in=ln,
+                           gn_partials=gnp, **extra))
+            ol.append(ops.gn_mish_apply_op(bufC, gnp, r["g1_w"], r["g1_b"], (self.tb, k * tb_ld + tb_off[bi]), ln,
+                                           bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0))
+            ol.append(conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp))
+            ol.append(conv(xin, cin, T, r["r_w"], r["r_b"], bufR, C, T, [0], ld_in=ld_in, len_in=ln, **extra))
             ol.append(ops.resblock_tail_op(bufC, gnp, r["g2_w"], r["g2_b"], ln, bufR, (self.ss, ss_off[bi]),
                                            (self.ss, ss_off[bi] + C), ss_ld, out, B, T, C))
 
@@ -889,23 +881,19 @@ class InferencePlan:
         self.ref_mel = f(B, Tr, oc)
         self.midi, self.lft, self.ref_midi, self.ref_lft = f(B, T, 1), f(B, T, 1), f(B, Tr, 1), f(B, Tr, 1)
         self.zeros = f(B, T, oc)  # zero conditioning of the source rows (serenade.py:193-199)
-        # mu, built in place in h0 channels [oc, oc + cond): time-concat of reference and source rows.  The prompt
-        # pass, the source pass and the style encoder are independent (disjoint regions of h0 / the speaker buffer):
-        # three op lists, run side by side at small batch x length
-        small = ops.PARALLEL and B * L <= ops.PARALLEL_MAX_ROWS
+        ol = []
+        # mu, built in place in h0 channels [oc, oc + cond): time-concat of reference and source rows
+        ol += model.encoder.build_ops(self.ref_x, B, Tr, (h0, oc), L * cp0, cp0)
+        ol += model.encoder.build_ops(self.x, B, T, (h0, Tr * cp0 + oc), L * cp0, cp0)
         c0 = oc + ec
-        ref_ops = model.encoder.build_ops(self.ref_x, B, Tr, (h0, oc), L * cp0, cp0)
-        ref_ops.append(ops.copy_channels_op(self.ref_midi, Tr, 1, 0, h0, L * cp0, cp0, c0, B, Tr, 1))
-        ref_ops.append(ops.copy_channels_op(self.ref_lft, Tr, 1, 0, h0, L * cp0, cp0, c0 + 1, B, Tr, 1))
-        ref_ops.append(ops.copy_channels_op(self.ref_mel, Tr * oc, oc, 0, h0, L * cp0, cp0, c0 + 2, B, Tr, oc))
-        with ops.workspace_slot(1 if small else 0):
-            src_ops = model.encoder.build_ops(self.x, B, T, (h0, Tr * cp0 + oc), L * cp0, cp0)
-        src_ops.append(ops.copy_channels_op(self.midi, T, 1, 0, (h0, Tr * cp0), L * cp0, cp0, c0, B, T, 1))
-        src_ops.append(ops.copy_channels_op(self.lft, T, 1, 0, (h0, Tr * cp0), L * cp0, cp0, c0 + 1, B, T, 1))
-        src_ops.append(ops.copy_channels_op(self.zeros, T * oc, oc, 0, (h0, Tr * cp0), L * cp0, cp0, c0 + 2, B, T, oc))
-        with ops.workspace_slot(2 if small else 0):
-            gst_ops = model.gst.build_ops(self.ref_mel, B, Tr, pl.spk)  # style vector -> the plan's speaker buffer
-        ol = [ops.Parallel([ref_ops, src_ops, gst_ops], dev)] if small else ref_ops + src_ops + gst_ops
+        ol.append(ops.copy_channels_op(self.ref_midi, Tr, 1, 0, h0, L * cp0, cp0, c0, B, Tr, 1))
+        ol.append(ops.copy_channels_op(self.ref_lft, Tr, 1, 0, h0, L * cp0, cp0, c0 + 1, B, Tr, 1))
+        ol.append(ops.copy_channels_op(self.ref_mel, Tr * oc, oc, 0, h0, L * cp0, cp0, c0 + 2, B, Tr, oc))
+        ol.append(ops.copy_channels_op(self.midi, T, 1, 0, (h0, Tr * cp0), L * cp0, cp0, c0, B, T, 1))
+        ol.append(ops.copy_channels_op(self.lft, T, 1, 0, (h0, Tr * cp0), L * cp0, cp0, c0 + 1, B, T, 1))
+        ol.append(ops.copy_channels_op(self.zeros, T * oc, oc, 0, (h0, Tr * cp0), L * cp0, cp0, c0 + 2, B, T, oc))
+        # style vector straight into the estimator plan's speaker buffer
+        ol += model.gst.build_ops(self.ref_mel, B, Tr, pl.spk)
         self.ops = ol
         self._runner = ops.GraphRunner(lambda: self.ops)
         self._sched = euler_schedule(n_timesteps)

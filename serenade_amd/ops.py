@@ -4,7 +4,6 @@ Tensors are torch CUDA fp32 tensors used as device memory only; every wrapper pa
 pointers, sizes and the current HIP stream.  All activations are channels-last (B, T, C).
 Nothing here computes on the host and nothing falls back to torch ops or to ``oracle/``.
 """
-import contextlib
 import ctypes
 import os
 
@@ -113,64 +112,8 @@ class ConvOp:
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_conv_gemm")
 
 
-_WS_SLOT = 0  # which per-device workspace ops built right now are bound to (side-stream branches use their own)
-
-
-@contextlib.contextmanager
-def workspace_slot(i):
-    """Ops built inside bind slot i of the split-K workspaces: every concurrently running branch of a `Parallel`
-    needs its own, ops of one stream share one."""
-    global _WS_SLOT
-    old, _WS_SLOT = _WS_SLOT, int(i)
-    try:
-        yield
-    finally:
-        _WS_SLOT = old
-
-
-# Independent op chains on side streams (res_conv next to conv1 -> GroupNorm -> conv2; HiFi-GAN's residual blocks;
-# the two encoder passes and GST).  Pays only while a launch cannot fill the chip: plans use it for
-# batch x frames <= PARALLEL_MAX_ROWS.  SERENADE_AMD_PARALLEL=0 turns it off.
-PARALLEL = os.environ.get("SERENADE_AMD_PARALLEL", "1") != "0"
-PARALLEL_MAX_ROWS = 2048
-
-
-class Parallel:
-    """Run op lists concurrently: branch 0 on the caller's stream, branch i > 0 on side stream i, forked after
-    everything already queued on the caller's stream and joined back before anything queued later (so the whole is
-    ordered like one op; inside a hipGraph capture the fork / join events become graph edges).  Branches must not
-    touch each other's outputs or scratch, and their split-K ops must be built under `workspace_slot(i)`."""
-
-    def __init__(self, branches, device):
-        self.branches = [list(b) for b in branches if len(b)]
-        self.streams, self.fork, self.joins = [], None, []
-        if PARALLEL and torch.device(device).type == "cuda" and len(self.branches) > 1:
-            self.streams = [torch.cuda.Stream(device=device) for _ in self.branches[1:]]
-            self.fork = torch.cuda.Event()
-            self.joins = [torch.cuda.Event() for _ in self.streams]
-
-    def __call__(self, stream=None):
-        if not self.streams or PROFILE is not None or stream is not None:
-            for br in self.branches:
-                for op in br:
-                    op(stream) if stream is not None else op()
-            return
-        main = torch.cuda.current_stream()
-        self.fork.record(main)
-        for s, br, ev in zip(self.streams, self.branches[1:], self.joins):
-            s.wait_event(self.fork)
-            h = ctypes.c_void_p(s.cuda_stream)
-            for op in br:
-                op(h)
-            ev.record(s)
-        for op in self.branches[0]:
-            op()
-        for ev in self.joins:
-            main.wait_event(ev)
-
-
 def splitk_workspace(device):
-    key = (str(device), _WS_SLOT)
+    key = str(device)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
     return _SPLITK_WS[key]
@@ -311,11 +254,6 @@ def transpose_op(src, dst, B, R, Cc, src_bs, ld_src, dst_bs, ld_dst):
 
 def renorm_op(x, trg_scale, trg_mean, voc_mean, voc_scale, y, rows, C):
     return CallOp("srn_renorm", (x, trg_scale, trg_mean, voc_mean, voc_scale, y, rows, C))
-
-
-def stage_mean_op(parts, out, n, div):
-    a = list(parts) + [None] * (4 - len(parts))
-    return CallOp("srn_stage_mean", (a[0], a[1], a[2], a[3], out, int(n), float(div)))
 
 
 def out_conv_tanh_op(x, w, bias, y, B, T, C, k, slope):

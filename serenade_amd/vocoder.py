@@ -195,60 +195,41 @@ class HiFiGANPlan:
         ol.append(conv(self.c_in, gen.in_channels, T, P["in_w"], P["in_b"], h, C0, T, ops.conv_taps(gen.kernel_size)))
         cur, ccur, tcur = h, C0, T
         nb = gen.num_blocks
-        # small batches: the residual blocks of a stage (kernel sizes 3 / 7 / 11) are independent chains over the same
-        # input -- each gets its own scratch and a side stream, and srn_stage_mean forms ((r0 + r1) + r2) / nb after
-        # the join instead of the running sum in the last conv's epilogue
-        small = ops.PARALLEL and B * T <= ops.PARALLEL_MAX_ROWS and 2 <= nb <= 4
-        extra_sets = [tuple(f(B * big) for _ in range(4)) for _ in range(nb - 1)] if small else []
-        self._keep2 = extra_sets
-
-        def resblock(convs, x, C, Tn, pp, xt, dst_last, fin_last):
-            bl = []
-            for idx, cv in enumerate(convs):
-                last = idx == len(convs) - 1
-                dst = dst_last if last else pp[idx % 2]
-                fin = fin_last if last else {}
-                if "w2" in cv and C in FUSED_UNIT_CHANNELS and (cv["k"] - 1) * cv["d"] <= 50 and cv["k"] % 2 == 1:
-                    # thin stage: the whole unit in one launch (resunit.hip); stage sum / mean in its epilogue
-                    bl.append(ops.ResUnitOp(x=x, w1=cv["w1"], b1=cv["b1"], w2=cv["w2"], b2=cv["b2"], out=dst,
-                                            n_batch=B, T=Tn, C=C, k=cv["k"], dilation=cv["d"], slope=slope,
-                                            res2=fin.get("res2"), post_div=fin.get("post_div", 0.0)))
-                elif "w2" in cv:
-                    bl.append(conv(x, C, Tn, cv["w1"], cv["b1"], xt, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
-                                   pro_act=ACT_LEAKY, pro_slope=slope))
-                    bl.append(conv(xt, C, Tn, cv["w2"], cv["b2"], dst, C, Tn, ops.conv_taps(cv["k"], 1),
-                                   pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,
-                                   ld_res=C, **fin))
-                else:
-                    bl.append(conv(x, C, Tn, cv["w1"], cv["b1"], dst, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
-                                   pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,
-                                   ld_res=C, **fin))
-                x = dst
-            return bl
-
         for i, up in enumerate(P["ups"]):
             s, C, Tn = up["s"], up["cout"], Ts[i]
             for r, (taps, wp) in enumerate(up["phases"]):
                 ol.append(conv(cur, ccur, tcur, wp, up["b"], u, C, tcur, taps, pro_act=ACT_LEAKY, pro_slope=slope,
                                out_bs=Tn * C, out_t_stride=s, out_t_off=r))
-            if small:
-                branches, outs = [], []
-                for j in range(nb):
-                    q0, q1, qt, qr = (p0, p1, xt, acc) if j == 0 else extra_sets[j - 1]
-                    with ops.workspace_slot(j):
-                        branches.append(resblock(P["blocks"][i * nb + j], u, C, Tn, [q0, q1], qt, qr, {}))
-                    outs.append(qr)
-                ol.append(ops.Parallel(branches, dev))
-                ol.append(ops.stage_mean_op(outs, acc, B * Tn * C, float(nb)))
-            else:
-                for j in range(nb):
+            for j in range(nb):
+                convs = P["blocks"][i * nb + j]
+                x = u
+                pp = [p0, p1]
+                for idx, cv in enumerate(convs):
+                    last = idx == len(convs) - 1
+                    dst = acc if last else pp[idx % 2]
                     fin = {}
-                    # cs += block(c); c = cs / num_blocks  (hifigan.py:183-186), in the reference's order
-                    if j > 0:
-                        fin.update(res2=acc, res2_bs=Tn * C, ld_res2=C)
-                    if j == nb - 1:
-                        fin.update(post=POST_DIV, post_div=float(nb))
-                    ol += resblock(P["blocks"][i * nb + j], u, C, Tn, [p0, p1], xt, acc, fin)
+                    if last:
+                        # cs += block(c); c = cs / num_blocks  (hifigan.py:183-186), in the reference's order
+                        if j > 0:
+                            fin.update(res2=acc, res2_bs=Tn * C, ld_res2=C)
+                        if j == nb - 1:
+                            fin.update(post=POST_DIV, post_div=float(nb))
+                    if "w2" in cv and C in FUSED_UNIT_CHANNELS and (cv["k"] - 1) * cv["d"] <= 50 and cv["k"] % 2 == 1:
+                        # thin stage: the whole unit in one launch (resunit.hip); stage sum / mean in its epilogue
+                        ol.append(ops.ResUnitOp(x=x, w1=cv["w1"], b1=cv["b1"], w2=cv["w2"], b2=cv["b2"], out=dst,
+                                                n_batch=B, T=Tn, C=C, k=cv["k"], dilation=cv["d"], slope=slope,
+                                                res2=fin.get("res2"), post_div=fin.get("post_div", 0.0)))
+                    elif "w2" in cv:
+                        ol.append(conv(x, C, Tn, cv["w1"], cv["b1"], xt, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
+                                       pro_act=ACT_LEAKY, pro_slope=slope))
+                        ol.append(conv(xt, C, Tn, cv["w2"], cv["b2"], dst, C, Tn, ops.conv_taps(cv["k"], 1),
+                                       pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,
+                                       ld_res=C, **fin))
+                    else:
+                        ol.append(conv(x, C, Tn, cv["w1"], cv["b1"], dst, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
+                                       pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,
+                                       ld_res=C, **fin))
+                    x = dst
             cur, ccur, tcur = acc, C, Tn
             # the next stage's upsample reads `acc` and writes `u`; resblocks then overwrite acc only at their end
         ol.append(ops.out_conv_tanh_op(cur, P["out_w"], P["out_b"], self.wave, B, tcur, ccur, gen.kernel_size, 0.01))

@@ -249,13 +249,6 @@ def emul_call(name, a):
             n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
             hh = (1 - z) * n + z * hh
         _v(h, B * H).reshape(B, H)[:] = hh
-    elif name == "srn_stage_mean":
-        x0, x1, x2, x3, out, n, div = a
-        acc = _v(x0, n) + _v(x1, n)
-        for extra in (x2, x3):
-            if extra is not None:
-                acc = acc + _v(extra, n)
-        _v(out, n)[:] = acc / div
     elif name == "srn_reflect_pad":
         x, out, B, n, pad, ld = a
         xv = _v(x, B * n).reshape(B, n)

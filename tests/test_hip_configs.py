@@ -175,31 +175,3 @@ def test_rccl_group_of_one(dev, precision):
     mg = out["multi_gpu"]
     assert mg["world_size_seen"] == 1 and mg["backend"] == "nccl" and len(mg["per_rank_ms_per_step"]) == 1
     assert out["value"] > 0 and mg["rank0_gather_ms_per_step"] >= 0
-
-
-def test_side_stream_branches_change_nothing(dev, voc):
-    """small batches run independent chains on side streams (ops.Parallel: the 1 x 1 shortcut of every ResnetBlock1D,
-    HiFi-GAN's three residual blocks per stage, prompt / source / style passes of Serenade.inference): bit-identical
-    to the same plans built serially, run to run, and under hipGraph replay"""
-    from serenade_amd import ops
-    d = synth_inputs(1, 80, T_ref=48, seed=41)
-    outs = []
-    saved = ops.PARALLEL
-    try:
-        for par in (True, False, True):
-            ops.PARALLEL = par
-            m = models.Serenade(**SERENADE_PARAMS)
-            m.load_state_dict(serenade_weights())
-            m = m.eval().to(dev)
-            voc.model._plans.clear()
-            mel = infer(m, d, dev, noise=d["z"])
-            wave, _ = voc.decode(mel)
-            torch.cuda.synchronize()
-            outs.append((mel.clone(), wave.clone()))
-    finally:
-        ops.PARALLEL = saved
-        voc.model._plans.clear()
-    n_par = sum(isinstance(op, ops.Parallel) for op in voc.model.plan(1, 80).ops)
-    assert n_par == 4, "one Parallel per HiFi-GAN stage at this size"
-    for mel, wave in outs[1:]:
-        assert torch.equal(mel, outs[0][0]) and torch.equal(wave, outs[0][1])
