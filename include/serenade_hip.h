@@ -187,7 +187,8 @@ int srn_out_conv_tanh(const float* x, const float* w, const float* bias, float* 
  * intermediate `xt` never leaves LDS, weights stream through a double-buffered LDS stage -- one HBM read and one
  * write per unit instead of five passes.  Optionally the stage bookkeeping of HiFiGANGenerator.forward
  * (hifigan.py:183-186) rides in the epilogue:  y = (y + res2) / post_div.
- *   x, out, res2: (n_batch, T, C) channels-last fp32, rows contiguous (ld = C); out must not alias x.
+ *   x, out, res2: (n_batch, T, C) channels-last fp32, rows contiguous (ld = C); out must not alias x (res2 may be
+ *   out: in-place running sum).
  *   w1, w2: packed [C][k * C] fp32 (tap-major, as srn_conv_gemm's k-major weights); b1, b2: (C).
  *   w1_hi, w2_hi: SRN_PREC_BF16X3 only -- the same weights as bf16 planes [C][k][C / 32][hi 32 | lo 32].
  */

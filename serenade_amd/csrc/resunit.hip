@@ -326,11 +326,12 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
     zero_acc();
     conv_pass(1);
 
-    // ---- epilogue: + b2 + x [+ res2] [/ post_div]; rows [t0, t0 + BMo) and < T.  out never aliases x / res2, so
-    //      the loads of a row quad are issued together and nothing is preloaded across sub-tiles (register budget)
+    // ---- epilogue: + b2 + x [+ res2] [/ post_div]; rows [t0, t0 + BMo) and < T.  out never aliases x; res2 may be
+    //      out itself (running stage sum): every element is loaded by the lane that later stores it.  The loads of a
+    //      row quad are issued together and nothing is preloaded across sub-tiles (register budget)
     const float* __restrict__ xz = p.x + (int64_t)z * p.x_bs + (int64_t)t0 * C;
-    const float* __restrict__ qz = p.res2 ? p.res2 + (int64_t)z * p.res2_bs + (int64_t)t0 * C : nullptr;
-    float* __restrict__ oz = p.out + (int64_t)z * p.out_bs + (int64_t)t0 * C;
+    const float* qz = p.res2 ? p.res2 + (int64_t)z * p.res2_bs + (int64_t)t0 * C : nullptr;  // may alias out
+    float* oz = p.out + (int64_t)z * p.out_bs + (int64_t)t0 * C;
     const bool divide = p.post_div != 0.f && p.post_div != 1.f;
     const int row_end = min(BMo, T - t0);
     __builtin_amdgcn_sched_barrier(0);
