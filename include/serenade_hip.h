@@ -80,7 +80,8 @@ typedef struct SrnConvParams {
   int32_t n_taps;
   int32_t tap_off[SRN_MAX_TAPS];
   int32_t in_stride;
-  int32_t pad_reflect; /* 0: zero padding, 1: reflection */
+  int32_t pad_reflect; /* 0: zero padding, 1: reflection at the tensor's ends, 2: reflection at 0 and at the item's own
+                        * end len_in[zb] (exact ragged batches: what nn.ReflectionPad1d does to the unpadded item) */
   int32_t w_nmajor;    /* 0: w is [N][n_taps*C_in] (k contiguous); 1: w is [K][N] (n contiguous), n_taps == 1 */
   int32_t pro_act;
   float pro_slope;
@@ -135,10 +136,13 @@ int64_t srn_conv_gemm_workspace_bytes(const SrnConvParams* p);
  * ResnetBlock1D; decoder.py:71-77,96-97).  Statistics come from the per-tile partials written by
  * srn_conv_gemm and run over the full padded length T (as the reference's GroupNorm does).
  *   x, y: (B, T, C); gamma, beta: (C); time_bias: (C) at time_bias + b * time_bias_bs, or NULL; lens: (B) or NULL.
+ * valid_stats = 1 (exact ragged batches): the statistics run over the item's own lens[b] rows -- the producing conv
+ * must have zeroed its padded rows (len_out) so that they add nothing to the partial sums -- which makes every item of a
+ * padded batch equal to its B = 1 run; 0 = the reference's batched semantics above.
  */
 int srn_gn_mish_apply(const float* x, const float* gn_partials, const float* gamma, const float* beta,
                       const float* time_bias, int64_t time_bias_bs, const int32_t* lens, float* y, int B, int T,
-                      int C, int groups, float eps, void* stream);
+                      int C, int groups, float eps, int valid_stats, void* stream);
 
 /*
  * Tail of ResnetBlock1D (decoder.py:98-101, 34-45):
@@ -147,7 +151,8 @@ int srn_gn_mish_apply(const float* x, const float* gn_partials, const float* gam
  */
 int srn_resblock_tail(const float* c2, const float* gn_partials, const float* gamma, const float* beta,
                       const int32_t* lens, const float* r, const float* scale, const float* shift, int64_t ld_ss,
-                      float* y, int B, int T, int C, int groups, float gn_eps, float ln_eps, void* stream);
+                      float* y, int B, int T, int C, int groups, float gn_eps, float ln_eps, int valid_stats,
+                      void* stream);
 
 /* nn.LayerNorm over the last dim (transformer.py:211,249): x, y (rows, C). */
 int srn_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
@@ -166,6 +171,12 @@ int srn_sinusoidal_emb(const float* t, float* out, int n, int dim, int ld, float
 /* Generic channels-last copy with channel offset/strides: dst[b,t,dc0+c] = src[b,t,sc0+c] * a + bvec?  (pack/concat) */
 int srn_copy_channels(const float* src, int64_t src_bs, int ld_src, int sc0, float* dst, int64_t dst_bs, int ld_dst,
                       int dc0, int B, int T, int C, void* stream);
+
+/* Ragged time-concat (serenade.py:202 `cat([ref_mu, src_mu], dim=1)` per item of a batch whose prompts differ in
+ * length): rows [0, n_rows[b]) of src item b -> dst rows row_off[b] + r, channels [dc0, dc0 + C).  NULL row_off = 0,
+ * NULL n_rows = T. */
+int srn_scatter_rows(const float* src, int64_t src_bs, int ld_src, float* dst, int64_t dst_bs, int ld_dst, int dc0,
+                     const int32_t* row_off, const int32_t* n_rows, int B, int T, int C, void* stream);
 
 /* (B, C, T) <-> (B, T, C) transposes at the API edge (reference tensors are (B, C, T); decoder.py:405-467). */
 int srn_transpose_ct(const float* src, float* dst, int B, int R, int Cc, int64_t src_bs, int ld_src, int64_t dst_bs,

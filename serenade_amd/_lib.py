@@ -55,9 +55,10 @@ _SIGS = {
     "srn_conv_gemm": (c_int, [POINTER(SrnConvParams), _P]),
     "srn_conv_gemm_workspace_bytes": (c_int64, [POINTER(SrnConvParams)]),
     "srn_hifigan_resunit": (c_int, [POINTER(SrnResUnitParams), _P]),
-    "srn_gn_mish_apply": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "srn_gn_mish_apply": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "srn_resblock_tail": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int,
-                                  c_float, c_float, _P]),
+                                  c_float, c_float, c_int, _P]),
+    "srn_scatter_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "srn_layernorm": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "srn_softmax_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "srn_sinusoidal_emb": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),

@@ -9,9 +9,11 @@ reference's; the program itself is organised as a small job object around the HI
         --outdir OUT --checkpoint checkpoint.pkl [--config config.yml] [--verbose 1]
 
 Per source utterance `U` and reference style `S` it writes `U_gt.wav`, `00_S_reference.wav`, `U_S.wav` (16-bit
-PCM) and the transposed F0 contour as dataset `lf0` of `U_S.h5` (`.npz` when the dump is `.npz`).  Utterances are
-converted one at a time (B = 1) on purpose: GroupNorm statistics of the estimator run over an utterance's padded
-length (decoder.py:71-77), so padding utterances into a common batch would change their output.  With
+PCM) and the transposed F0 contour as dataset `lf0` of `U_S.h5` (`.npz` when the dump is `.npz`).  By default every
+(utterance, style) pair is one B = 1 call, like the reference: GroupNorm statistics of the estimator run over an
+item's padded length (decoder.py:71-77), so naive padding into a batch would change the output.  `--batch-styles`
+converts all styles of an utterance in one *exact* ragged batch (`Serenade.inference_ragged`: per-item GroupNorm
+statistics, per-item reflection padding, per-item prompt / source offsets), whose results equal the loop's.  With
 `torchrun --nproc-per-node N` the utterance list is split contiguously over the ranks (one GPU each).
 """
 import argparse
@@ -76,6 +78,10 @@ def build_parser():
     p.add_argument("--outdir", type=str, required=True, help="where the converted audio and F0 files go")
     p.add_argument("--checkpoint", type=str, required=True, help="model checkpoint (its ['model'] entry is loaded)")
     p.add_argument("--verbose", type=int, default=1, help="0: warnings only, 1: info, 2+: debug (default 1)")
+    p.add_argument("--batch-styles", action="store_true",
+                   help="(MI355X build only) convert all reference styles of an utterance in ONE ragged batch "
+                        "(Serenade.inference_ragged: every item is computed exactly as its own B = 1 call, so the "
+                        "outputs equal the default style-by-style loop) -- fills the GPU instead of running B = 1")
     return p
 
 
@@ -163,6 +169,7 @@ class DecodeJob:
         if self.styles is None:  # drawn once, for the first utterance, then kept (ssc_decode.py:375-376)
             self.styles = get_random_ref_style(self.args.dumpdir, utt, self.ext)
         done = 0
+        jobs = []  # (style, prompt tensors, transposed F0) in style order
         for style, path in self.styles.items():
             if style in utt:  # a prompt of the utterance's own style would be a reconstruction
                 continue
@@ -170,12 +177,18 @@ class DecodeJob:
             ref = self.prompt(path)
             write_wav_pcm16(os.path.join(out, f"00_{style}_reference.wav"), ref["wave"], self.sr)
             # NB: linear_midi_shift edits item["lf0"] in place, so later styles start from the shifted contour --
-            # the reference behaves the same way (ssc_decode.py:424)
-            lf0 = linear_midi_shift(item["lf0"], ref["f0"])
-            mel = self.model.inference(x, lengths, score, loud, ref["cvec"], ref["lens"], ref["mel"], ref["score"],
-                                       ref["loud"])
-            wave, _ = self.vocoder.decode(mel.squeeze(0))
-            write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0.astype(np.float32))
+            # the reference behaves the same way (ssc_decode.py:424); snapshot what it would write for this style
+            lf0 = linear_midi_shift(item["lf0"], ref["f0"]).astype(np.float32)
+            jobs.append((style, ref, lf0))
+        if self.args.batch_styles and len(jobs) > 1:
+            mels = self.model.inference_ragged(
+                [(x[0], score[0], loud[0], r["cvec"][0], r["mel"][0], r["score"][0], r["loud"][0]) for _, r, _ in jobs])
+        else:
+            mels = [self.model.inference(x, lengths, score, loud, r["cvec"], r["lens"], r["mel"], r["score"], r["loud"])
+                    for _, r, _ in jobs]
+        for (style, _, lf0), mel in zip(jobs, mels):
+            wave, _ = self.vocoder.decode(mel.squeeze(0) if mel.dim() == 3 else mel)
+            write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0)
             write_wav_pcm16(os.path.join(out, f"{utt}_{style}.wav"), wave.cpu().numpy(), self.sr)
             done += x.shape[1]
         return done

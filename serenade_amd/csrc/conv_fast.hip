@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
 #pragma unroll
     for (int i = 0; i < C::A_LD; ++i) {
       int ti = a_tb[i] + toff;
-      if (p.pad_reflect) {
+      if (p.pad_reflect) {  // 2: mirror at the item's own end (ragged batches), else at the tensor's end
+        const int T_ref = p.pad_reflect == 2 ? len_in : T_in;
         if (ti < 0) ti = -ti;
-        if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
+        if (ti >= T_ref) ti = 2 * (T_ref - 1) - ti;
       }
       const bool ok = ti >= 0 && ti < len_in;
       aptr[i] = ok ? src + (int64_t)ti * ld + c4 * 4 : g_zero_page + c4 * 4;

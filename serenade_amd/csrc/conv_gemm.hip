@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const SrnConvParams p
 #pragma unroll
       for (int i = 0; i < C::A_LD; ++i) {
         int ti = a_tb[i] + toff;
-        if (p.pad_reflect) {
+        if (p.pad_reflect) {  // 2: mirror at the item's own end (ragged batches), else at the tensor's end
+          const int T_ref = p.pad_reflect == 2 ? len_in : T_in;
           if (ti < 0 && ti > -(1 << 28)) ti = -ti;
-          if (ti >= T_in) ti = 2 * (T_in - 1) - ti;
+          if (ti >= T_ref) ti = 2 * (T_ref - 1) - ti;
         }
         const bool ok = cok && ti >= 0 && ti < len_in;
         R.a_ok |= (ok ? 1u : 0u) << i;

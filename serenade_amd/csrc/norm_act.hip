@@ -10,8 +10,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics from the per-(32 rows x 32 cols) partials the conv epilogue wrote.
 // partials: [b][gn_mt][gn_nt][2];  out: mean[g], rstd[g] in LDS.  Called by all 256 threads.
+// n_rows: rows the statistics run over -- T (the reference's batched semantics: padded frames included), or the item's
+// own length when the producing conv zeroed its padded rows (exact ragged batches: the B = 1 result of every item).
 __device__ __forceinline__ void group_stats(const float* __restrict__ partials, int b, int T, int C, int groups,
-                                            float eps, float* s_mean, float* s_rstd) {
+                                            float eps, float* s_mean, float* s_rstd, int n_rows) {
   const int gn_mt = (T + 31) / 32;
   const int gn_nt = C / 32;
   const int nt_per_g = (C / groups) / 32;
@@ -30,7 +32,7 @@ __device__ __forceinline__ void group_stats(const float* __restrict__ partials, 
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
     if (lane == 0) {
-      const double cnt = (double)T * (double)(C / groups);
+      const double cnt = (double)max(n_rows, 1) * (double)(C / groups);
       const double mean = s1 / cnt;
       double var = s2 / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -49,13 +51,14 @@ __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restr
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ time_bias,
                                                             const int32_t* __restrict__ lens, float* __restrict__ y,
-                                                            int T, int C, int groups, float eps, int64_t tb_bs) {
+                                                            int T, int C, int groups, float eps, int64_t tb_bs,
+                                                            int valid_stats) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * GN_ROWS;
   if (time_bias) time_bias += (int64_t)b * tb_bs;
-  group_stats(partials, b, T, C, groups, eps, s_mean, s_rstd);
   const int len = lens ? min(lens[b], T) : T;
+  group_stats(partials, b, T, C, groups, eps, s_mean, s_rstd, valid_stats ? len : T);
   const int c4n = C / 4;
   const int cpg = C / groups;
   const int rows = min(GN_ROWS, T - r0);
@@ -96,12 +99,12 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(
     const float* __restrict__ c2, const float* __restrict__ partials, const float* __restrict__ gamma,
     const float* __restrict__ beta, const int32_t* __restrict__ lens, const float* __restrict__ rres,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ld_ss, float* __restrict__ y, int T,
-    int C, int groups, float gn_eps, float ln_eps) {
+    int C, int groups, float gn_eps, float ln_eps, int valid_stats) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * TAIL_ROWS;
-  group_stats(partials, b, T, C, groups, gn_eps, s_mean, s_rstd);
   const int len = lens ? min(lens[b], T) : T;
+  group_stats(partials, b, T, C, groups, gn_eps, s_mean, s_rstd, valid_stats ? len : T);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c4n = C / 4;
   const int cpg = C / groups;
@@ -290,6 +293,21 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int64_t src_
   }
 }
 
+// ragged time-concat: rows [0, n_rows[b]) of item b go to dst rows row_off[b] + r (channels dc0 .. dc0 + C)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int64_t src_bs, int ld_src,
+                                    float* __restrict__ dst, int64_t dst_bs, int ld_dst, int dc0,
+                                    const int32_t* __restrict__ row_off, const int32_t* __restrict__ n_rows, int T,
+                                    int C) {
+  const int b = blockIdx.y;
+  const int off = row_off ? row_off[b] : 0;
+  const int64_t total = (int64_t)min(n_rows ? n_rows[b] : T, T) * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(idx / C), c = (int)(idx - (int64_t)t * C);
+    dst[(int64_t)b * dst_bs + (int64_t)(off + t) * ld_dst + dc0 + c] = src[(int64_t)b * src_bs + (int64_t)t * ld_src + c];
+  }
+}
+
 // dst[b][c][r] = src[b][r][c]  (32x32 LDS tile transpose)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
                                                         int Cc, int64_t src_bs, int ld_src, int64_t dst_bs,
@@ -393,13 +411,14 @@ __global__ __launch_bounds__(256) void out_conv_tanh_generic(const float* __rest
 // =================================================================================================
 extern "C" int srn_gn_mish_apply(const float* x, const float* gn_partials, const float* gamma, const float* beta,
                                  const float* time_bias, int64_t time_bias_bs, const int32_t* lens, float* y, int B,
-                                 int T, int C, int groups, float eps, void* stream) {
+                                 int T, int C, int groups, float eps, int valid_stats, void* stream) {
   SRN_CHECK_ARG(x && gn_partials && gamma && beta && y, "gn_mish_apply: null pointer");
+  SRN_CHECK_ARG(!valid_stats || lens, "gn_mish_apply: valid_stats needs lens");
   SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
                 "gn_mish_apply: need (C / groups) %% 32 == 0 (C=%d groups=%d)", C, groups);
   dim3 grid((T + GN_ROWS - 1) / GN_ROWS, B);
   hipLaunchKernelGGL(gn_mish_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gn_partials, gamma, beta,
-                     time_bias, lens, y, T, C, groups, eps, time_bias_bs);
+                     time_bias, lens, y, T, C, groups, eps, time_bias_bs, valid_stats);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -407,14 +426,15 @@ extern "C" int srn_gn_mish_apply(const float* x, const float* gn_partials, const
 extern "C" int srn_resblock_tail(const float* c2, const float* gn_partials, const float* gamma, const float* beta,
                                  const int32_t* lens, const float* r, const float* scale, const float* shift,
                                  int64_t ld_ss, float* y, int B, int T, int C, int groups, float gn_eps,
-                                 float ln_eps, void* stream) {
+                                 float ln_eps, int valid_stats, void* stream) {
   SRN_CHECK_ARG(c2 && gn_partials && gamma && beta && r && scale && shift && y, "resblock_tail: null pointer");
+  SRN_CHECK_ARG(!valid_stats || lens, "resblock_tail: valid_stats needs lens");
   SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "resblock_tail: C=%d unsupported", C);
   SRN_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
                 "resblock_tail: need (C / groups) %% 32 == 0");
   dim3 grid((T + TAIL_ROWS - 1) / TAIL_ROWS, B);
   hipLaunchKernelGGL(resblock_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2, gn_partials, gamma, beta,
-                     lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps);
+                     lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -467,6 +487,18 @@ extern "C" int srn_copy_channels(const float* src, int64_t src_bs, int ld_src, i
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, src, src_bs,
                      ld_src, sc0, dst, dst_bs, ld_dst, dc0, T, C);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_scatter_rows(const float* src, int64_t src_bs, int ld_src, float* dst, int64_t dst_bs, int ld_dst,
+                                int dc0, const int32_t* row_off, const int32_t* n_rows, int B, int T, int C,
+                                void* stream) {
+  SRN_CHECK_ARG(src && dst && B > 0 && T > 0 && C > 0, "scatter_rows: bad args");
+  int64_t blocks = ((int64_t)T * C + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, src, src_bs,
+                     ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, T, C);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -217,9 +217,10 @@ class Decoder(_Packed):
         self._packed = P
         return P
 
-    def plan(self, B, L, n_steps, euler, per_sample_t=False):
-        key = (B, L, n_steps, bool(euler), bool(per_sample_t), ops.DEFAULT_PRECISION)
-        return _lru_get(self._plans, key, 8, lambda: DecoderPlan(self, B, L, n_steps, euler, per_sample_t))
+    def plan(self, B, L, n_steps, euler, per_sample_t=False, exact_ragged=False):
+        key = (B, L, n_steps, bool(euler), bool(per_sample_t), bool(exact_ragged), ops.DEFAULT_PRECISION)
+        return _lru_get(self._plans, key, 8,
+                        lambda: DecoderPlan(self, B, L, n_steps, euler, per_sample_t, exact_ragged))
 
     @torch.no_grad()
     def forward(self, x, mask, mu, t, speaker_features):
@@ -260,7 +261,13 @@ class DecoderPlan:
                  (flow_matching.py:84-91), written in place into channels [0, out_ch) of h0.
     euler=False: one estimator call, output (B, L, out_ch) in ``self.dphi``."""
 
-    def __init__(self, dec, B, L, n_steps, euler, per_sample_t=False):
+    def __init__(self, dec, B, L, n_steps, euler, per_sample_t=False, exact_ragged=False):
+        # exact_ragged: every item of a padded batch gets the result of its own B = 1 run.  The one op of the estimator
+        # whose result depends on an item's padding is GroupNorm (the reference normalises over the padded length,
+        # decoder.py:71-77); here the convs that feed a GroupNorm zero their padded rows (len_out), so those add nothing
+        # to the partial sums, and the statistics are divided by the item's own length (valid_stats).
+        rg = bool(exact_ragged)
+        self.exact_ragged = rg
         P = dec.packed()
         dev = dec._device()
         # per_sample_t: ONE estimator call whose time embedding has one row per batch item
@@ -354,14 +361,15 @@ class DecoderPlan:
             if xin1 is not None:
                 extra = dict(in1=xin1, C_in0=cin0, in1_bs=T * (cin - cin0), ld_in1=cin - cin0)
             t3 = ops.conv_taps(3)
+            zero_pad = dict(len_out=ln) if rg else {}
             ol.append(conv(xin, cin, T, r["c1_w"], r["c1_b"], bufC, C, T, t3, ld_in=ld_in, len_in=ln,
-                           gn_partials=gnp, **extra))
+                           gn_partials=gnp, **zero_pad, **extra))
             ol.append(ops.gn_mish_apply_op(bufC, gnp, r["g1_w"], r["g1_b"], (self.tb, k * tb_ld + tb_off[bi]), ln,
-                                           bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0))
-            ol.append(conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp))
+                                           bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0, valid_stats=rg))
+            ol.append(conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp, **zero_pad))
             ol.append(conv(xin, cin, T, r["r_w"], r["r_b"], bufR, C, T, [0], ld_in=ld_in, len_in=ln, **extra))
             ol.append(ops.resblock_tail_op(bufC, gnp, r["g2_w"], r["g2_b"], ln, bufR, (self.ss, ss_off[bi]),
-                                           (self.ss, ss_off[bi] + C), ss_ld, out, B, T, C))
+                                           (self.ss, ss_off[bi] + C), ss_ld, out, B, T, C, valid_stats=rg))
 
         def tfm(ol, bi, lvl, X, C):
             t = P["tfm"][bi]
@@ -446,8 +454,9 @@ class DecoderPlan:
             # final block + projection (+ fused Euler update)
             C = ccur
             ln = self.lens[0]
-            ol.append(conv(cur, C, L, P["fb_w"], P["fb_b"], bufC, C, L, ops.conv_taps(3), len_in=ln, gn_partials=gnp))
-            ol.append(ops.gn_mish_apply_op(bufC, gnp, P["fg_w"], P["fg_b"], None, ln, bufA, B, L, C))
+            ol.append(conv(cur, C, L, P["fb_w"], P["fb_b"], bufC, C, L, ops.conv_taps(3), len_in=ln, gn_partials=gnp,
+                           **(dict(len_out=ln) if rg else {})))
+            ol.append(ops.gn_mish_apply_op(bufC, gnp, P["fg_w"], P["fg_b"], None, ln, bufA, B, L, C, valid_stats=rg))
             if euler:
                 ol.append(conv(bufA, C, L, P["fp_w"], P["fp_b"], self.h0, oc, L, [0], len_out=ln, res=self.h0,
                                res_mode=RES_AXPY, beta=dt, res_bs=L * cp0, ld_res=cp0, out_bs=L * cp0, ld_out=cp0))
@@ -620,8 +629,10 @@ class Conv1dResnet(_Packed):
             self._packed = P
         return self._packed
 
-    def build_ops(self, x, B, T, out, out_bs, ld_out):
-        """x: (B, T, in_dim) device tensor; writes (B, T, out_dim) rows into `out` (tensor or (tensor, off))."""
+    def build_ops(self, x, B, T, out, out_bs, ld_out, lens=None):
+        """x: (B, T, in_dim) device tensor; writes (B, T, out_dim) rows into `out` (tensor or (tensor, off)).
+        lens (int32 device tensor (B,)): items are shorter than T; the ReflectionPad1d layers then mirror at each
+        item's own end, as they do for the unpadded item (rows beyond an item's length hold unspecified values)."""
         P = self.packed()
         dev = self._device()
         Hd = self.hidden_dim
@@ -633,18 +644,19 @@ class Conv1dResnet(_Packed):
                           ld_in0=cin, ldw=w.shape[1], out_bs=kw.pop("out_bs", T * cout), ld_out=kw.pop("ld_out", cout),
                           bias=b, taps=taps, **kw)
 
-        ol = [conv(x, self.in_dim, P["in_w"], P["in_b"], h, Hd, ops.conv_taps(7), reflect=True)]
+        rf = dict(reflect=True) if lens is None else dict(reflect=2, len_in=lens)
+        ol = [conv(x, self.in_dim, P["in_w"], P["in_b"], h, Hd, ops.conv_taps(7), **rf)]
         cur, nxt = h, h2
         for blk in P["blocks"]:
             d = blk["d"]
             ol.append(conv(cur, Hd, blk["sc_w"], blk["sc_b"], s, Hd, [0]))
-            ol.append(conv(cur, Hd, blk["c3_w"], blk["c3_b"], b1, Hd, ops.conv_taps(3, d), reflect=True,
-                           pro_act=ACT_LEAKY, pro_slope=0.2))
+            ol.append(conv(cur, Hd, blk["c3_w"], blk["c3_b"], b1, Hd, ops.conv_taps(3, d), pro_act=ACT_LEAKY,
+                           pro_slope=0.2, **rf))
             ol.append(conv(b1, Hd, blk["c1_w"], blk["c1_b"], nxt, Hd, [0], pro_act=ACT_LEAKY, pro_slope=0.2, res=s,
                            res_mode=RES_ADD, res_bs=T * Hd, ld_res=Hd))
             cur, nxt = nxt, cur
-        ol.append(conv(cur, Hd, P["out_w"], P["out_b"], out, self.out_dim, ops.conv_taps(7), reflect=True,
-                       pro_act=ACT_LEAKY, pro_slope=0.2, out_bs=out_bs, ld_out=ld_out))
+        ol.append(conv(cur, Hd, P["out_w"], P["out_b"], out, self.out_dim, ops.conv_taps(7), pro_act=ACT_LEAKY,
+                       pro_slope=0.2, out_bs=out_bs, ld_out=ld_out, **rf))
         return ol
 
     @torch.no_grad()
@@ -836,6 +848,25 @@ class Serenade(_Packed):
             spks=speaker_features, mask_l=mask_l, draws=draws)
         return ret
 
+    @torch.inference_mode()
+    def inference_ragged(self, items, n_timesteps=10, temperature=0.667, noises=None):
+        """Several conversions in ONE batch, each exactly what `inference` returns for it alone (B = 1): `items` is a
+        list of (x (T,in), midi (T,1), lft (T,1), ref_x (R,in), ref_logmel (R,out), ref_midi (R,1), ref_lft (R,1));
+        T and R may differ per item.  Returns a list of (T, out) tensors.  `noises` (optional list of (out, R + T)
+        tensors) replaces the draws; by default the noise of item b is drawn on the CPU generator in item order, as a
+        loop of B = 1 calls would (flow_matching.py:57-60).  This is what the decode CLI batches its styles with."""
+        if len(items) == 0:
+            raise ValueError("Serenade.inference_ragged: no items")
+        _require_cuda(items[0][0], "Serenade.inference_ragged")
+        shapes = tuple((int(it[0].shape[0]), int(it[3].shape[0])) for it in items)
+        key = ("ragged", shapes, n_timesteps, ops.DEFAULT_PRECISION)
+        rp = _lru_get(self._plans, key, 4, lambda: RaggedInferencePlan(self, shapes, n_timesteps))
+        rp.load(items)
+        dev = items[0][0].device
+        if noises is None:
+            noises = [torch.randn((1, self.output_dim, t + r)).to(dev)[0] * temperature for t, r in shapes]
+        return rp.run(noises)
+
     def _inference_plan(self, B, T, Tr, n_timesteps):
         key = (B, T, Tr, n_timesteps, ops.DEFAULT_PRECISION)
         return _lru_get(self._plans, key, 8, lambda: InferencePlan(self, B, T, Tr, n_timesteps))
@@ -860,6 +891,71 @@ class Serenade(_Packed):
         mel = ip.run(z, total).permute(0, 2, 1)  # (B, L, oc)
         mel = mel[:, int(ref_lengths[0]):, :]
         return mel.squeeze(0)
+
+
+class RaggedInferencePlan:
+    """`Serenade.inference_ragged`: a batch of conversions whose source AND prompt lengths differ, every item computed
+    exactly as its own B = 1 call (the reference's decode loop, ssc_decode.py:346-438, is B = 1 by construction).
+    Per item b the sequence is [prompt rows (R_b) | source rows (T_b)] from row 0, padded to the batch maximum:
+    * the two content-encoder passes mirror at each item's own end (`pad_reflect = 2`);
+    * prompt conditioning is written from row 0, source conditioning is scattered to row R_b (`srn_scatter_rows`);
+    * the style encoder runs per item (its conv stack / GRU see the whole prompt: no masking exists there);
+    * the estimator plan is built `exact_ragged` (GroupNorm over valid rows)."""
+
+    def __init__(self, model, shapes, n_timesteps):
+        dev = model._device()
+        self.shapes = shapes = [(int(t), int(r)) for t, r in shapes]
+        B = self.B = len(shapes)
+        Tm, Rm = max(t for t, _ in shapes), max(r for _, r in shapes)
+        Lm = self.Lm = max(t + r for t, r in shapes)
+        oc, ec = model.output_dim, model.encoder_channels
+        self.pl = pl = model.cfm_decoder.estimator.plan(B, Lm, n_timesteps, euler=True, exact_ragged=True)
+        h0, cp0 = pl.h0, pl.h0.shape[2]
+        f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+        self.x, self.ref_x = f(B, Tm, model.input_dim), f(B, Rm, model.input_dim)
+        self.ref_mel = f(B, Rm, oc)
+        self.midi, self.lft, self.ref_midi, self.ref_lft = f(B, Tm, 1), f(B, Tm, 1), f(B, Rm, 1), f(B, Rm, 1)
+        self.zeros, self.enc_src = f(B, Tm, oc), f(B, Tm, ec)
+        self.t_len, self.r_len = i32([t for t, _ in shapes]), i32([r for _, r in shapes])
+        c0 = oc + ec
+        ol = model.encoder.build_ops(self.ref_x, B, Rm, (h0, oc), Lm * cp0, cp0, lens=self.r_len)
+        ol.append(ops.copy_channels_op(self.ref_midi, Rm, 1, 0, h0, Lm * cp0, cp0, c0, B, Rm, 1))
+        ol.append(ops.copy_channels_op(self.ref_lft, Rm, 1, 0, h0, Lm * cp0, cp0, c0 + 1, B, Rm, 1))
+        ol.append(ops.copy_channels_op(self.ref_mel, Rm * oc, oc, 0, h0, Lm * cp0, cp0, c0 + 2, B, Rm, oc))
+        # source rows start where the item's prompt ends (they overwrite whatever the padded prompt rows left there)
+        ol += model.encoder.build_ops(self.x, B, Tm, self.enc_src, Tm * ec, ec, lens=self.t_len)
+        for src, ch, width in ((self.enc_src, oc, ec), (self.midi, c0, 1), (self.lft, c0 + 1, 1),
+                               (self.zeros, c0 + 2, oc)):
+            ol.append(ops.scatter_rows_op(src, Tm * width, width, h0, Lm * cp0, cp0, ch, self.r_len, self.t_len, B, Tm,
+                                          width))
+        for b, (_, r) in enumerate(shapes):
+            ol += model.gst.build_ops((self.ref_mel, b * Rm * oc), 1, r, (pl.spk, b * pl.spk.shape[1]))
+        self.ops = ol
+        self._runner = ops.GraphRunner(lambda: self.ops)
+        self._sched = euler_schedule(n_timesteps)
+        self._z = f(B, oc, Lm)
+
+    def load(self, items):
+        """items: per conversion (x, midi, lft, ref_x, ref_logmel, ref_midi, ref_lft), 2-D tensors"""
+        for b, it in enumerate(items):
+            t, r = self.shapes[b]
+            for buf, src, n in ((self.x, it[0], t), (self.midi, it[1], t), (self.lft, it[2], t), (self.ref_x, it[3], r),
+                                (self.ref_mel, it[4], r), (self.ref_midi, it[5], r), (self.ref_lft, it[6], r)):
+                buf[b, :n].copy_(src.detach().reshape(n, -1), non_blocking=True)
+
+    def run(self, noises):
+        pl = self.pl
+        for b, z in enumerate(noises):  # (oc, L_b) each
+            self._z[b, :, : z.shape[-1]].copy_(z.reshape(self._z.shape[1], -1), non_blocking=True)
+        pl.set_schedule(*self._sched)
+        pl.set_lens(torch.tensor([t + r for t, r in self.shapes]))
+        pl._xin.copy_(self._z, non_blocking=True)
+        pl.load_ops[0]()
+        self._runner()
+        pl.run()
+        out = pl.read_out()  # (B, oc, Lm)
+        return [out[b, :, r:r + t].t().contiguous() for b, (t, r) in enumerate(self.shapes)]
 
 
 class InferencePlan:

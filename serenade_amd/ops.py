@@ -68,7 +68,7 @@ class ConvOp:
         p.n_taps = len(taps)
         for i, t in enumerate(taps):
             p.tap_off[i] = t
-        p.in_stride, p.pad_reflect, p.w_nmajor = int(in_stride), int(bool(reflect)), int(bool(w_nmajor))
+        p.in_stride, p.pad_reflect, p.w_nmajor = int(in_stride), int(reflect), int(bool(w_nmajor))  # reflect: 0 / 1 / 2
         p.pro_act, p.pro_slope, p.alpha, p.beta = int(pro_act), float(pro_slope), float(alpha), float(beta)
         p.geglu, p.res_mode, p.post, p.post_div = int(bool(geglu)), int(res_mode), int(post), float(post_div)
         p.out_t_stride, p.out_t_off, p.tile = int(out_t_stride), int(out_t_off), int(tile)
@@ -221,14 +221,20 @@ class CallOp:
 
 
 # ------------------------------------------------------------------ op builders (return CallOp)
-def gn_mish_apply_op(x, partials, gamma, beta, time_bias, lens, y, B, T, C, groups=8, eps=1e-5, tb_bs=0):
-    return CallOp("srn_gn_mish_apply", (x, partials, gamma, beta, time_bias, tb_bs, lens, y, B, T, C, groups, eps))
+def gn_mish_apply_op(x, partials, gamma, beta, time_bias, lens, y, B, T, C, groups=8, eps=1e-5, tb_bs=0,
+                     valid_stats=False):
+    return CallOp("srn_gn_mish_apply", (x, partials, gamma, beta, time_bias, tb_bs, lens, y, B, T, C, groups, eps,
+                                        int(bool(valid_stats))))
 
 
 def resblock_tail_op(c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups=8, gn_eps=1e-5,
-                     ln_eps=1e-5):
+                     ln_eps=1e-5, valid_stats=False):
     return CallOp("srn_resblock_tail", (c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups,
-                                        gn_eps, ln_eps))
+                                        gn_eps, ln_eps, int(bool(valid_stats))))
+
+
+def scatter_rows_op(src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C):
+    return CallOp("srn_scatter_rows", (src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C))
 
 
 def layernorm_op(x, gamma, beta, y, rows, C, eps=1e-5):

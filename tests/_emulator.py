@@ -63,8 +63,9 @@ def emul_conv(kw):
             for j, off in enumerate(taps):
                 ti = t * in_stride + off
                 if g("reflect", False):
+                    t_ref = li if int(g("reflect")) == 2 else T_in  # 2: mirror at the item's own end
                     ti = torch.where(ti < 0, -ti, ti)
-                    ti = torch.where(ti >= T_in, 2 * (T_in - 1) - ti, ti)
+                    ti = torch.where(ti >= t_ref, 2 * (t_ref - 1) - ti, ti)
                 valid = ((ti >= 0) & (ti < li)).float().unsqueeze(1)
                 tic = ti.clamp(0, T_in - 1)
                 base = o_in0 + zb * g("in0_bs", 0) + zh * g("in0_hs", 0)
@@ -138,12 +139,12 @@ def _v(x, n=None):
     return f[o:] if n is None else f[o:o + n]
 
 
-def _group_stats(partials, b, T, C, groups, eps):
+def _group_stats(partials, b, T, C, groups, eps, n_rows=None):
     mt, nt = (T + 31) // 32, C // 32
     p = _v(partials)[b * mt * nt * 2:(b + 1) * mt * nt * 2].reshape(mt, nt, 2).double()
     per = (C // groups) // 32
     s = p.reshape(mt, groups, per, 2).sum(dim=(0, 2))
-    cnt = T * (C // groups)
+    cnt = max(T if n_rows is None else n_rows, 1) * (C // groups)
     mean = s[:, 0] / cnt
     var = (s[:, 1] / cnt - mean * mean).clamp_min(0)
     return mean.float(), (1.0 / torch.sqrt(var + eps)).float()
@@ -151,10 +152,11 @@ def _group_stats(partials, b, T, C, groups, eps):
 
 def emul_call(name, a):
     if name == "srn_gn_mish_apply":
-        x, part, gamma, beta, tb, tb_bs, lens, y, B, T, C, groups, eps = a
+        x, part, gamma, beta, tb, tb_bs, lens, y, B, T, C, groups, eps, valid = a
         xv, yv = _v(x, B * T * C).reshape(B, T, C), _v(y, B * T * C).reshape(B, T, C)
+        lens = None if lens is None else _v(lens)
         for b in range(B):
-            mean, rstd = _group_stats(part, b, T, C, groups, eps)
+            mean, rstd = _group_stats(part, b, T, C, groups, eps, min(int(lens[b]), T) if valid else None)
             m = mean.repeat_interleave(C // groups)
             r = rstd.repeat_interleave(C // groups)
             o = F.mish((xv[b] - m) * r * gamma + beta)
@@ -164,10 +166,11 @@ def emul_call(name, a):
             o[ln:] = 0
             yv[b] = o
     elif name == "srn_resblock_tail":
-        c2, part, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups, ge, le = a
+        c2, part, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups, ge, le, valid = a
         xv, rv, yv = (_v(t, B * T * C).reshape(B, T, C) for t in (c2, r, y))
+        lens = None if lens is None else _v(lens)
         for b in range(B):
-            mean, rstd = _group_stats(part, b, T, C, groups, ge)
+            mean, rstd = _group_stats(part, b, T, C, groups, ge, min(int(lens[b]), T) if valid else None)
             m = mean.repeat_interleave(C // groups)
             rs = rstd.repeat_interleave(C // groups)
             o = F.mish((xv[b] - m) * rs * gamma + beta)
@@ -249,6 +252,17 @@ def emul_call(name, a):
             n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
             hh = (1 - z) * n + z * hh
         _v(h, B * H).reshape(B, H)[:] = hh
+    elif name == "srn_scatter_rows":
+        src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C = a
+        sv, dv = _v(src), _v(dst)
+        ro = None if row_off is None else _v(row_off)
+        nr = None if n_rows is None else _v(n_rows)
+        for b in range(B):
+            off = 0 if ro is None else int(ro[b])
+            n = T if nr is None else min(int(nr[b]), T)
+            for t in range(n):
+                dv[b * dst_bs + (off + t) * ld_dst + dc0: b * dst_bs + (off + t) * ld_dst + dc0 + C] = \
+                    sv[b * src_bs + t * ld_src: b * src_bs + t * ld_src + C]
     elif name == "srn_reflect_pad":
         x, out, B, n, pad, ld = a
         xv = _v(x, B * n).reshape(B, n)

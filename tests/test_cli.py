@@ -127,6 +127,71 @@ def test_decode_cli_end_to_end(tmp_path):
     _cli_case(tmp_path, on_gpu=False)
 
 
+def _two_style_tree(tmp_path):
+    """dump with one utterance and two prompts of different lengths; returns the CLI argument list (no --outdir)"""
+    from joblib import dump
+    from sklearn.preprocessing import MinMaxScaler, StandardScaler
+    rng = np.random.default_rng(1)
+    for d in ("dump", "exp", "ref", "voc"):
+        (tmp_path / d).mkdir()
+    np.savez(tmp_path / "dump" / "EN_spk1_song_Control_Group_0001.npz", **_feats(rng, 20))
+    np.savez(tmp_path / "ref" / "breathy.npz", **_feats(rng, 13))
+    np.savez(tmp_path / "ref" / "falsetto.npz", **_feats(rng, 18))
+    scaler = {"logmel": StandardScaler().fit(rng.standard_normal((50, 80))),
+              "hubert": StandardScaler().fit(rng.standard_normal((50, 32))),
+              "score": MinMaxScaler().fit(np.array([[30.0], [80.0]])),
+              "loud": MinMaxScaler().fit(np.array([[-50.0], [0.0]]))}
+    dump(scaler, tmp_path / "stats.joblib")
+    sd = fill_state_dict(_shapes.as_meta(_shapes.serenade_shapes(**MODEL_PARAMS)), seed=3)
+    torch.save({"model": sd}, tmp_path / "exp" / "checkpoint.pkl")
+    gsd = fill_state_dict(_shapes.as_meta(_shapes.hifigan_shapes(**GEN_PARAMS, weight_norm=True)), seed=4)
+    torch.save({"model": {"generator": gsd}}, tmp_path / "voc" / "vocoder.pkl")
+    yaml.safe_dump({"generator_params": GEN_PARAMS, "sampling_rate": 24000, "format": "hdf5"},
+                   open(tmp_path / "voc" / "config.yml", "w"))
+    np.savez(tmp_path / "voc" / "stats.npz", mean=np.zeros(80, np.float32), scale=np.ones(80, np.float32))
+    yaml.safe_dump({"model_type": "Serenade", "model_params": MODEL_PARAMS, "sampling_rate": 24000,
+                    "vocoder": {"checkpoint": str(tmp_path / "voc" / "vocoder.pkl"),
+                                "config": str(tmp_path / "voc" / "config.yml"),
+                                "stats": str(tmp_path / "voc" / "stats.npz")}},
+                   open(tmp_path / "exp" / "config.yml", "w"))
+    json.dump({"Breathy": str(tmp_path / "ref" / "breathy.npz"), "Falsetto": str(tmp_path / "ref" / "falsetto.npz")},
+              open(tmp_path / "refs.json", "w"))
+    return ["--dumpdir", str(tmp_path / "dump"), "--stats", str(tmp_path / "stats.joblib"), "--ref-dict",
+            str(tmp_path / "refs.json"), "--checkpoint", str(tmp_path / "exp" / "checkpoint.pkl"), "--verbose", "0"]
+
+
+def _batch_styles_case(tmp_path, on_gpu):
+    import contextlib
+    argv = _two_style_tree(tmp_path)
+    outs = {}
+    with (contextlib.nullcontext() if on_gpu else _emulator.installed()):
+        for name, extra in (("loop", []), ("batch", ["--batch-styles"])):
+            torch.manual_seed(7)
+            ssc_decode.main(argv + ["--outdir", str(tmp_path / name)] + extra)
+            outs[name] = sorted(os.listdir(tmp_path / name))
+    assert outs["loop"] == outs["batch"] and len(outs["loop"]) == 7  # gt + 2 x (reference, wav, lf0)
+    for f in outs["loop"]:
+        a, b = tmp_path / "loop" / f, tmp_path / "batch" / f
+        if f.endswith(".wav"):
+            with wavmod.open(str(a)) as fa, wavmod.open(str(b)) as fb:
+                pa = np.frombuffer(fa.readframes(fa.getnframes()), dtype="<i2").astype(np.int32)
+                pb = np.frombuffer(fb.readframes(fb.getnframes()), dtype="<i2").astype(np.int32)
+            assert pa.shape == pb.shape and np.abs(pa - pb).max() <= 1, f
+        else:
+            assert np.array_equal(np.load(a)["lf0"], np.load(b)["lf0"]), f
+
+
+def test_batch_styles_equals_the_style_loop(tmp_path):
+    """--batch-styles: one exact ragged batch per utterance (different prompt lengths) == the B = 1 style loop"""
+    _batch_styles_case(tmp_path, on_gpu=False)
+
+
+@pytest.mark.gpu
+def test_batch_styles_equals_the_style_loop_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    _batch_styles_case(tmp_path, on_gpu=True)
+
+
 @pytest.mark.gpu
 def test_decode_cli_end_to_end_gpu(tmp_path):
     """the same case through libserenade_hip.so on cuda:0 (B = 1 loop, files, PCM_16, lf0) vs the CPU oracle"""

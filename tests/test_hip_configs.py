@@ -158,6 +158,30 @@ def test_reloading_weights_into_a_model_that_has_run(dev):
     assert torch.equal(a1, b1)
 
 
+def test_exact_ragged_batch_equals_b1_runs(dev, model):
+    """Serenade.inference_ragged: items with different source AND prompt lengths in one padded batch, each equal to its
+    own B = 1 `inference` call (GroupNorm over valid rows, reflection at the item's end, per-item row offsets)"""
+    shapes = [(200, 96), (131, 160), (257, 33), (64, 64)]
+    items, noises, singles = [], [], []
+    for i, (t, r) in enumerate(shapes):
+        d = synth_inputs(1, t, T_ref=r, seed=500 + i)
+        g = lambda k: d[k][0].to(dev)
+        items.append((g("x"), g("midi"), g("lft"), g("ref_x"), g("ref_logmel"), g("ref_midi"), g("ref_lft")))
+        noises.append(d["z"][0].to(dev))
+        singles.append(infer(model, d, dev, noise=d["z"]))
+    outs = model.inference_ragged(items, noises=noises)
+    for (t, _), o, s in zip(shapes, outs, singles):
+        assert o.shape == (t, 80) and nerr(o, s) < 2e-5
+    # default noise: drawn per item in order on the CPU generator, like a loop of B = 1 calls
+    torch.manual_seed(3)
+    a = model.inference_ragged(items[:2])
+    torch.manual_seed(3)
+    b = [model.inference(it[0][None], torch.tensor([it[0].shape[0]]), it[1][None], it[2][None], it[3][None],
+                         torch.tensor([it[3].shape[0]]), it[4][None], it[5][None], it[6][None]) for it in items[:2]]
+    for o, s in zip(a, b):
+        assert nerr(o, s) < 2e-5
+
+
 def test_rccl_group_of_one(dev, precision):
     """C4 rehearsal on one GPU: bench.py initialises the RCCL ("nccl") process group with device_id before any other
     GPU call and runs its step + waveform gather under it (world size 1, a child process)."""

@@ -320,7 +320,20 @@ def test_norm_and_elementwise_kernels(dev):
     lens = torch.tensor([75, 44], dtype=torch.int32)
     gam, bet, tb = 1 + 0.1 * rnd(C, seed=34), 0.1 * rnd(C, seed=35), rnd(4 * C, seed=36)
     e = _run_call(dev, "srn_gn_mish_apply", [x, _partials(x), gam, bet, (tb, C), 0, lens, torch.zeros(B, Tn, C), B,
-                                             Tn, C, 8, 1e-5])
+                                             Tn, C, 8, 1e-5, 0])
+    assert e < KTOL.k
+    # valid_stats: statistics over each item's own rows (its padded rows zeroed by the producing conv) == the
+    # GroupNorm of the unpadded item
+    xz = x * (torch.arange(Tn)[None] < lens[:, None]).float().unsqueeze(-1)
+    yv = torch.zeros(B, Tn, C, device=dev)
+    ops.gn_mish_apply_op(xz.to(dev), _partials(xz).to(dev), gam.to(dev), bet.to(dev), None, lens.to(dev), yv, B, Tn, C,
+                         valid_stats=True)()
+    for b in range(B):
+        n = int(lens[b])
+        one = F.mish(F.group_norm(x[b:b + 1, :n].transpose(1, 2), 8, gam, bet, 1e-5)).transpose(1, 2)
+        assert nerr(yv[b:b + 1, :n], one) < KTOL.k and yv[b, n:].abs().max().item() == 0
+    e = _run_call(dev, "srn_gn_mish_apply", [xz, _partials(xz), gam, bet, None, 0, lens, torch.zeros(B, Tn, C), B, Tn,
+                                             C, 8, 1e-5, 1])
     assert e < KTOL.k
     # against torch's GroupNorm directly (statistics over the padded length)
     y = torch.zeros(B, Tn, C, device=dev)
@@ -330,8 +343,16 @@ def test_norm_and_elementwise_kernels(dev):
     assert nerr(y, ref) < KTOL.k
     ss = rnd(B, 4 * C, seed=37)
     e = _run_call(dev, "srn_resblock_tail", [x, _partials(x), gam, bet, lens, rnd(B, Tn, C, seed=38), (ss, C),
-                                             (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5])
+                                             (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5, 0])
     assert e < KTOL.k
+    e = _run_call(dev, "srn_resblock_tail", [xz, _partials(xz), gam, bet, lens, rnd(B, Tn, C, seed=38), (ss, C),
+                                             (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5, 1])
+    assert e < KTOL.k
+    src = rnd(2, 9, 5, seed=44)
+    e = _run_call(dev, "srn_scatter_rows", [src, 45, 5, torch.zeros(2, 16, 8), 128, 8, 2,
+                                            torch.tensor([3, 7], dtype=torch.int32),
+                                            torch.tensor([9, 4], dtype=torch.int32), 2, 9, 5])
+    assert e == 0
     e = _run_call(dev, "srn_layernorm", [x.reshape(-1, C), gam, bet, torch.zeros(B * Tn, C), B * Tn, C, 1e-5])
     assert e < KTOL.k
     for L, ld in ((70, 72), (300, 300), (1280, 1280), (2176, 2176)):

@@ -108,6 +108,26 @@ def test_inference_uses_cpu_generator_like_reference(model):
     assert torch.equal(a, b)
 
 
+def test_exact_ragged_batch_equals_b1_runs(model):
+    """inference_ragged: three items with different source and prompt lengths in one padded batch; every item equals
+    its own B = 1 inference() and the oracle (per-item GroupNorm statistics, reflection at the item's end, offsets)"""
+    shapes = [(24, 16), (17, 21), (31, 9)]
+    ds = [synth_inputs(1, t, T_ref=r, seed=70 + i) for i, (t, r) in enumerate(shapes)]
+    items = [tuple(d[k][0] for k in ("x", "midi", "lft", "ref_x", "ref_logmel", "ref_midi", "ref_lft")) for d in ds]
+    with _emulator.installed():
+        outs = model.inference_ragged(items, noises=[d["z"][0] for d in ds])
+        singles = [model.inference(d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
+                                   d["ref_logmel"], d["ref_midi"], d["ref_lft"], noise=d["z"]) for d in ds]
+        with pytest.raises(ValueError):
+            model.inference_ragged([])
+    w = serenade_weights()
+    for (t, _), o, s, d in zip(shapes, outs, singles, ds):
+        assert o.shape == (t, 80) and nerr(o, s) < 2e-5
+        ref = O.serenade_inference(w, d["x"], d["lengths"], d["midi"], d["lft"], d["ref_x"], d["ref_lengths"],
+                                   d["ref_logmel"], d["ref_midi"], d["ref_lft"], d["z"], n_timesteps=10)
+        assert nerr(o, ref) < 1e-4
+
+
 def _gen(small=False, wn=True):
     w, params = hifigan_weights(seed=1 if small else 0, small=small)
     g = vocoder.HiFiGANGenerator(**params)
