@@ -267,6 +267,42 @@ int srn_logmel(const float* spec, const float* mel_t, float* out, int64_t frames
 int srn_loudness(const float* spec, const float* a_weight_db, uint32_t* gmax_ws, float* out, int B, int frames,
                  int n_bins, int ld, float amin, float top_db, float add_eps, void* stream);
 
+/*
+ * Training step of the estimator: the backward of the decoder blocks that CFM.compute_loss
+ * differentiates (flow_matching.py:95-133 -> matcha_components/decoder.py:34-45,66-101,384-467, transformer.py:120-146,
+ * 286-352) and the optimizer update (bin/ssc_train.py:331-349, trainers/ssc.py:86-96).  GEMM-shaped gradients (dgrad of
+ * convs / projections, dP, dQ) are srn_conv_gemm launches with transposed weights; these are the HBM-bound pieces.
+ * Column sums come back as per-row-chunk partial sums the host adds (bit-reproducible, no atomics).
+ */
+/* y[b,t,:] = LayerNorm_C(x[b,t,:]) * m[b] + a[b]  (no affine inside): nn.LayerNorm with m = gamma, a = beta and batch
+ * strides 0; SpeakerAdapter (decoder.py:34-45) with m = W_scale spk + b, a = W_bias spk + b and batch strides C. */
+int srn_rowln_fwd(const float* x, const float* m, int64_t m_bs, const float* a, int64_t a_bs, float* y, int B, int T,
+                  int C, float eps, void* stream);
+/* dx of the above; partial (B, srn_rowln_chunks(T), 2, C): [0] = sum_t dy * xhat (-> dm), [1] = sum_t dy (-> da). */
+int srn_rowln_bwd(const float* x, const float* dy, const float* m, int64_t m_bs, float* dx, float* partial, int B, int T,
+                  int C, float eps, void* stream);
+int srn_rowln_chunks(int T);
+/* Block1D's GroupNorm -> Mish -> mask (decoder.py:66-77) backward, statistics over the padded length T.
+ * mean, rstd (B, groups); step 1: partial (B, srn_gn_chunks(T), 2, C): [0] = sum_t dg, [1] = sum_t dg * xhat with
+ * dg = dy * mish'(gamma xhat + beta) on rows < lens[b]; the host forms d beta, d gamma and gsum (B, groups, 2) =
+ * per-group sums of (gamma * [0], gamma * [1]); step 2: dh = rstd (dg gamma - gsum0 / n - xhat gsum1 / n). */
+int srn_gn_mish_bwd_partial(const float* h, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const int32_t* lens, float* partial, int B, int T, int C, int groups,
+                            void* stream);
+int srn_gn_mish_bwd_apply(const float* h, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, const float* gsum, const int32_t* lens, float* dh, int B, int T, int C,
+                          int groups, void* stream);
+int srn_gn_chunks(int T);
+/* softmax backward in place on dp: dp <- scale * p o (dp - rowsum(dp o p)); rows of L with stride ld. */
+int srn_softmax_bwd(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream);
+/* GEGLU (transformer.py:120-146): hg (rows, 2 inner) = [h | g]; a = h * gelu_erf(g); backward dhg from da. */
+int srn_geglu_fwd(const float* hg, float* a, int64_t rows, int inner, void* stream);
+int srn_geglu_bwd(const float* hg, const float* da, float* dhg, int64_t rows, int inner, void* stream);
+/* torch.optim.AdamW step `step` (1-based) over one flat fp32 buffer: g is scaled by grad_scale first (the
+ * clip_grad_norm_ coefficient of trainers/ssc.py:90-94), then p *= 1 - lr wd; m, v updated; p -= lr/bc1 m/(sqrt(v/bc2)+eps). */
+int srn_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

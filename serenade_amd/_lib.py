@@ -75,6 +75,16 @@ _SIGS = {
     "srn_loudness": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P]),
     "srn_gru_recur_last": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "srn_style_token_attention_kv": (c_int, [_P] * 8 + [c_int] * 5 + [_P]),
+    "srn_rowln_fwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_float, _P]),
+    "srn_rowln_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "srn_rowln_chunks": (c_int, [c_int]),
+    "srn_gn_mish_bwd_partial": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
+    "srn_gn_mish_bwd_apply": (c_int, [_P] * 9 + [c_int] * 4 + [_P]),
+    "srn_gn_chunks": (c_int, [c_int]),
+    "srn_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P]),
+    "srn_geglu_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "srn_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "srn_adamw": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -1,0 +1,605 @@
+"""Training step of the flow-matching estimator on MI355X.
+
+What the reference does per step (trainers/ssc.py:57-96, bin/ssc_train.py:331-359): `Serenade.forward` -> CFM loss
+(+ prior loss) -> `backward()` -> DDP gradient all-reduce over NCCL -> `clip_grad_norm_` -> AdamW.  Of that, this module
+builds the part with the FLOPs -- the estimator (matcha_components/decoder.py `Decoder`, 192 parameter tensors) under
+`CFM.compute_loss` (flow_matching.py:95-133):
+
+  * `Estimator`      the decoder with the reference's parameter names and shapes, all views into ONE flat fp32 buffer
+                     (and one flat gradient buffer), forward written over the same channels-last HIP kernels as
+                     inference, every op an autograd node whose backward is HIP again;
+  * `GradSync`       the DDP replacement: the flat gradient buffer is all-reduced over RCCL in buckets that are
+                     launched from backward hooks as soon as their parameters are done (overlaps the rest of backward);
+  * `AdamW`          clip_grad_norm_ + torch.optim.AdamW as one fused kernel launch over the flat buffers (srn_adamw);
+  * `cfm_loss`       flow_matching.py:95-133 around the estimator.
+
+Division of labour.  GEMM-shaped gradients that contract over channels -- dgrad of every conv / projection (a conv of
+dY with the tap-reversed, transposed weights), dP = dO V^T and dQ = dS K of attention -- are `srn_conv_gemm` launches;
+row / column reductions and activations (GroupNorm+Mish, LayerNorm / SpeakerAdapter, softmax, GEGLU) are the kernels of
+csrc/train.hip.  Gradients that contract over TIME (wgrad = dY^T X, dV = P^T dO, dK = dS^T Q) are plain transposed-A
+GEMMs and go to rocBLAS through `torch.matmul` (the library-GEMM case).  torch autograd is the tape; mask multiplies,
+concatenations, the (B, 2048) time-embedding activations and scalar loss reductions are torch ops on the same device.
+The content encoder and the GST style encoder are NOT differentiated here: `mu` and `spks` are inputs, their gradients
+are returned for a caller that wants to continue (out of scope this round).  Dropout (p = 0.05 in the
+reference's transformer blocks while training) is not applied: parity is against the reference with dropout disabled.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .ops import ConvOp
+
+__all__ = ["Estimator", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} needs the HIP library and an MI355X tensor (there is no CPU fallback)")
+
+
+def _call(name, *args):
+    ops.CallOp(name, args)()
+
+
+def _rup(n, m):
+    return (n + m - 1) // m * m
+
+
+# =====================================================================================================================
+#  conv / linear
+# =====================================================================================================================
+def _launch_conv(x, w, bias, y, taps, B, T_in, T_out, C, N, in_stride=1, out_t_stride=1, out_t_off=0, ld_out=None,
+                 out_bs=None, gn_partials=None):
+    ConvOp(in0=x, w=w, out=y, n_batch=B, T_in=T_in, T_out=T_out, C_in=C, N=N, in0_bs=T_in * C, ld_in0=C,
+           ldw=w.shape[1], out_bs=(T_out * N if out_bs is None else out_bs), ld_out=(N if ld_out is None else ld_out),
+           bias=bias, taps=taps, in_stride=in_stride, out_t_stride=out_t_stride, out_t_off=out_t_off,
+           gn_partials=gn_partials, precision=_lib.PREC_FP32)()
+
+
+class _Conv(torch.autograd.Function):
+    """y[b, t, :] = sum_j x[b, t * stride + taps[j], :] W_j^T + bias  (rows outside [0, T) read as zero).
+    x (B, T, C) fp32 contiguous, C % 4 == 0; w packed (N, len(taps) * C), k-major; optional GroupNorm partial sums of
+    the output (32 x 32 tiles, conv epilogue) as a second, non-differentiable result."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, taps, stride, T_out, want_gn):
+        _require_cuda(x, "training.conv1d")
+        B, T, C = x.shape
+        N = w.shape[0]
+        x, w = x.contiguous(), w.contiguous()
+        y = torch.empty(B, T_out, N, device=x.device, dtype=torch.float32)
+        part = None
+        if want_gn:
+            part = torch.zeros(B, (T_out + 31) // 32, N // 32, 2, device=x.device, dtype=torch.float32)
+        _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part)
+        ctx.save_for_backward(x, w)
+        ctx.taps, ctx.stride, ctx.has_bias = tuple(taps), stride, bias is not None
+        if want_gn:
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        x, w = ctx.saved_tensors
+        taps, stride = ctx.taps, ctx.stride
+        B, T, C = x.shape
+        _, T_out, N = dy.shape
+        nt = len(taps)
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dgrad: dX[t] = sum_j dY[(t - taps[j]) / stride] W_j over the taps that divide -> a conv of dY with the
+            # transposed weights Wd[c][j][n] = W[n][j][c]; with stride 2 one launch per output-row parity
+            wd = w.view(N, nt, C).permute(2, 1, 0).contiguous()  # (C, nt, N)
+            dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
+            if stride == 1:
+                _launch_conv(dy, wd.view(C, nt * N), None, dx, [-o for o in taps], B, T_out, T, N, C)
+            else:
+                for ph in range(stride):
+                    sel = [j for j, o in enumerate(taps) if (ph - o) % stride == 0]
+                    rows = (T - ph + stride - 1) // stride
+                    if rows <= 0:
+                        continue
+                    if not sel:
+                        dx[:, ph::stride] = 0
+                        continue
+                    wsel = wd[:, sel, :].reshape(C, len(sel) * N).contiguous()
+                    _launch_conv(dy, wsel, None, dx, [(ph - taps[j]) // stride for j in sel], B, T_out, rows, N, C,
+                                 out_t_stride=stride, out_t_off=ph, ld_out=C, out_bs=T * C)
+        if ctx.needs_input_grad[1]:
+            # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- contraction over time: rocBLAS
+            lo, hi = min(min(taps), 0), max(max(taps), 0)
+            need = (T_out - 1) * stride + hi + 1
+            xp = F.pad(x, (0, 0, -lo, max(0, need - T)))
+            dyt = dy.transpose(1, 2)  # (B, N, T_out)
+            mats = []
+            for o in taps:
+                xs = xp[:, o - lo: o - lo + (T_out - 1) * stride + 1: stride]  # (B, T_out, C) view
+                mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
+            dw = torch.stack(mats, dim=1).reshape(N, nt * C)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 1))
+        return dx, dw, db, None, None, None, None
+
+
+def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False):
+    """channels-last conv / linear over the HIP contraction kernel.  x (B, T, C) or (rows, C); w packed (N, k * C)."""
+    two_d = x.dim() == 2
+    if two_d:
+        x = x.unsqueeze(0)
+    T = x.shape[1]
+    if stride == 1:
+        T_out = T
+    else:  # torch Conv1d with padding (k - 1) / 2: taps -p .. p
+        p = -min(taps)
+        T_out = (T + 2 * p - (len(taps) - 1) - 1) // stride + 1
+    out = _Conv.apply(x, w, bias, tuple(int(t) for t in taps), int(stride), int(T_out), bool(want_gn))
+    if two_d:
+        return out.squeeze(0)
+    return out
+
+
+def pack_conv(w, c_pad=None):
+    """torch Conv1d weight (N, C, k) -> (N, k * C_pad), differentiable (a permute + pad)."""
+    n, c, k = w.shape
+    wp = w.permute(0, 2, 1)
+    if c_pad is not None and c_pad > c:
+        wp = F.pad(wp, (0, c_pad - c))
+    return wp.reshape(n, -1)
+
+
+# =====================================================================================================================
+#  GroupNorm -> Mish -> mask   (Block1D, decoder.py:66-77)
+# =====================================================================================================================
+def _gn_stats(part, T, C, groups, eps):
+    """(mean, rstd) (B, groups) fp32 from the conv epilogue's 32 x 32 tile sums; statistics over the padded length"""
+    B, mt, nt, _ = part.shape
+    s = part.double().sum(1).view(B, groups, nt // groups, 2).sum(2)
+    cnt = float(T) * (C // groups)
+    mean = s[..., 0] / cnt
+    var = (s[..., 1] / cnt - mean * mean).clamp_min(0.0)
+    return mean.float().contiguous(), (1.0 / torch.sqrt(var + eps)).float().contiguous()
+
+
+class _GNMish(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, part, gamma, beta, lens, groups, eps):
+        B, T, C = h.shape
+        y = torch.empty_like(h)
+        _call("srn_gn_mish_apply", h, part, gamma, beta, None, 0, lens, y, B, T, C, groups, eps, 0)
+        mean, rstd = _gn_stats(part, T, C, groups, eps)
+        ctx.save_for_backward(h, mean, rstd, gamma, beta, lens)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, mean, rstd, gamma, beta, lens = ctx.saved_tensors
+        G = ctx.groups
+        B, T, C = h.shape
+        dy = dy.contiguous()
+        nch = (T + 31) // 32
+        part = torch.empty(B, nch, 2, C, device=h.device, dtype=torch.float32)
+        _call("srn_gn_mish_bwd_partial", h, dy, mean, rstd, gamma, beta, lens, part, B, T, C, G)
+        col = part.sum(1)  # (B, 2, C): sum_t dg, sum_t dg * xhat
+        dbeta, dgamma = col[:, 0].sum(0), col[:, 1].sum(0)
+        gsum = (col * gamma).view(B, 2, G, C // G).sum(-1).transpose(1, 2).contiguous()  # (B, G, 2)
+        dh = torch.empty_like(h)
+        _call("srn_gn_mish_bwd_apply", h, dy, mean, rstd, gamma, beta, gsum, lens, dh, B, T, C, G)
+        return dh, None, dgamma, dbeta, None, None, None
+
+
+def gn_mish(h, part, gamma, beta, lens, groups=8, eps=1e-5):
+    """mish(GroupNorm(h)) on rows < lens[b], zero after; `part` = the producing conv's GroupNorm partial sums."""
+    return _GNMish.apply(h.contiguous(), part, gamma.contiguous(), beta.contiguous(), lens, groups, eps)
+
+
+# =====================================================================================================================
+#  per-frame LayerNorm with a per-(batch, channel) multiplier / offset: nn.LayerNorm and SpeakerAdapter
+# =====================================================================================================================
+class _RowLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, a, eps):
+        B, T, C = x.shape
+        per_b = m.dim() == 2
+        y = torch.empty_like(x)
+        _call("srn_rowln_fwd", x, m, C if per_b else 0, a, C if per_b else 0, y, B, T, C, eps)
+        ctx.save_for_backward(x, m)
+        ctx.eps, ctx.per_b = eps, per_b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, m = ctx.saved_tensors
+        B, T, C = x.shape
+        dy = dy.contiguous()
+        nch = (T + 31) // 32
+        part = torch.empty(B, nch, 2, C, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _call("srn_rowln_bwd", x, dy, m, C if ctx.per_b else 0, dx, part, B, T, C, ctx.eps)
+        col = part.sum(1)  # (B, 2, C)
+        if ctx.per_b:
+            return dx, col[:, 0].contiguous(), col[:, 1].contiguous(), None
+        return dx, col[:, 0].sum(0), col[:, 1].sum(0), None
+
+
+def row_ln(x, m, a, eps=1e-5):
+    """y = LayerNorm_C(x) * m + a; m, a (C,) (nn.LayerNorm) or (B, C) (SpeakerAdapter, decoder.py:34-45)."""
+    return _RowLN.apply(x.contiguous(), m.contiguous(), a.contiguous(), eps)
+
+
+# =====================================================================================================================
+#  attention core: softmax(Q K^T / sqrt(d) + key mask) V on the fused (B, L, 3 * H * d) projection
+# =====================================================================================================================
+class _AttnCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, lens, H):
+        B, L, three = qkv.shape
+        inner = three // 3
+        hd = inner // H
+        Lp = _rup(L, 32)
+        dev = qkv.device
+        alpha = 1.0 / math.sqrt(hd)
+        P = torch.zeros(B, H, L, Lp, device=dev, dtype=torch.float32)
+        ConvOp(in0=qkv, w=(qkv, inner), out=P, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=hd, N=L,
+               in0_bs=L * three, in0_hs=hd, ld_in0=three, w_bs=L * three, w_hs=hd, ldw=three, out_bs=H * L * Lp,
+               out_hs=L * Lp, ld_out=Lp, alpha=alpha, precision=_lib.PREC_FP32)()
+        _call("srn_softmax_rows", P, lens, B * H, H, L, Lp)
+        vt = torch.zeros(B, inner, Lp, device=dev, dtype=torch.float32)  # V^T per head: (hd, Lp) k-major
+        vt[:, :, :L] = qkv[:, :, 2 * inner:].transpose(1, 2)
+        o = torch.empty(B, L, inner, device=dev, dtype=torch.float32)
+        ConvOp(in0=P, w=vt, out=o, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
+               in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * inner, out_hs=hd,
+               ld_out=inner, precision=_lib.PREC_FP32)()
+        ctx.save_for_backward(qkv, P)
+        ctx.H = H
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P = ctx.saved_tensors
+        H = ctx.H
+        B, L, three = qkv.shape
+        inner = three // 3
+        hd = inner // H
+        Lp = P.shape[-1]
+        dev = qkv.device
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        # dP = dO V^T (rows of dO against rows of V: the Q K^T launch with other operands), then dS in place
+        dS = torch.zeros(B, H, L, Lp, device=dev, dtype=torch.float32)
+        ConvOp(in0=do, w=(qkv, 2 * inner), out=dS, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=hd, N=L,
+               in0_bs=L * inner, in0_hs=hd, ld_in0=inner, w_bs=L * three, w_hs=hd, ldw=three, out_bs=H * L * Lp,
+               out_hs=L * Lp, ld_out=Lp, precision=_lib.PREC_FP32)()
+        _call("srn_softmax_bwd", P, dS, B * H * L, L, Lp, 1.0 / math.sqrt(hd))
+        # dQ = dS K: contraction over keys, K^T per head as the k-major operand
+        kt = torch.zeros(B, inner, Lp, device=dev, dtype=torch.float32)
+        kt[:, :, :L] = qkv[:, :, inner:2 * inner].transpose(1, 2)
+        ConvOp(in0=dS, w=kt, out=dqkv, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
+               in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * three, out_hs=hd,
+               ld_out=three, precision=_lib.PREC_FP32)()
+        # dK = dS^T Q, dV = P^T dO: contraction over query rows (transposed-A GEMMs): rocBLAS
+        q = qkv[:, :, :inner].view(B, L, H, hd).permute(0, 2, 1, 3)
+        doh = do.view(B, L, H, hd).permute(0, 2, 1, 3)
+        dk = torch.matmul(dS[..., :L].transpose(-1, -2), q)  # (B, H, L, hd)
+        dv = torch.matmul(P[..., :L].transpose(-1, -2), doh)
+        dqkv[:, :, inner:2 * inner] = dk.permute(0, 2, 1, 3).reshape(B, L, inner)
+        dqkv[:, :, 2 * inner:] = dv.permute(0, 2, 1, 3).reshape(B, L, inner)
+        return dqkv, None, None
+
+
+def attention_core(qkv, lens, n_head):
+    return _AttnCore.apply(qkv.contiguous(), lens, n_head)
+
+
+# =====================================================================================================================
+#  GEGLU
+# =====================================================================================================================
+class _Geglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hg):
+        rows, two = hg.numel() // hg.shape[-1], hg.shape[-1]
+        a = torch.empty(*hg.shape[:-1], two // 2, device=hg.device, dtype=torch.float32)
+        _call("srn_geglu_fwd", hg, a, rows, two // 2)
+        ctx.save_for_backward(hg)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        (hg,) = ctx.saved_tensors
+        rows, two = hg.numel() // hg.shape[-1], hg.shape[-1]
+        dhg = torch.empty_like(hg)
+        _call("srn_geglu_bwd", hg, da.contiguous(), dhg, rows, two // 2)
+        return dhg
+
+
+def geglu(hg):
+    """(.., 2 inner) = [h | g] -> h * gelu_erf(g)   (transformer.py:120-146)"""
+    return _Geglu.apply(hg.contiguous())
+
+
+# =====================================================================================================================
+#  the estimator
+# =====================================================================================================================
+def sinusoidal_pos_emb(t, dim, scale=1000.0):
+    """decoder.py:54-63 (no parameters): t (B,) -> (B, dim)"""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    f = torch.exp(torch.arange(half, device=t.device, dtype=torch.float32) * -e)
+    arg = scale * t.reshape(-1, 1).to(torch.float32) * f.unsqueeze(0)
+    return torch.cat((arg.sin(), arg.cos()), dim=-1)
+
+
+class Estimator:
+    """`Decoder` (matcha_components/decoder.py:196-467) for training: parameters under the reference's names and
+    shapes (`self.params`), each a view of the flat buffer `self.flat`; gradients are views of `self.flat_grad`.
+
+    `forward(x, mask, mu, t, spks)` takes the reference's layouts -- x (B, out_ch, L), mask (B, 1, L), mu (B, cond, L),
+    t (B,), spks (B, S) -- and returns (B, out_ch, L) with an autograd graph whose backward runs on the HIP kernels."""
+
+    N_HEAD, GROUPS = 4, 8
+
+    def __init__(self, state_dict, device):
+        names = [k for k in state_dict if not k.endswith("num_batches_tracked")]
+        sizes = [state_dict[k].numel() for k in names]
+        # 4-float alignment of every view (16-B loads in the kernels)
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += _rup(n, 4)
+        self.flat = torch.zeros(o, device=device, dtype=torch.float32)
+        self.flat_grad = torch.zeros(o, device=device, dtype=torch.float32)
+        self.params, self.spans = {}, {}
+        for k, off, n in zip(names, offs, sizes):
+            v = self.flat[off:off + n].view(state_dict[k].shape)
+            v.copy_(state_dict[k].to(torch.float32))
+            v.requires_grad_(True)
+            v.grad = self.flat_grad[off:off + n].view(state_dict[k].shape)
+            self.params[k] = v
+            self.spans[k] = (off, n)
+        self.device = device
+        self.n_down = sum(1 for k in names if k.startswith("down_blocks.") and k.endswith(".0.mlp.1.weight"))
+        self.n_mid = sum(1 for k in names if k.startswith("mid_blocks.") and k.endswith(".0.mlp.1.weight"))
+        self.n_up = sum(1 for k in names if k.startswith("up_blocks.") and k.endswith(".0.mlp.1.weight"))
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    # ---- blocks ------------------------------------------------------------------------------------------------
+    def _lin(self, x, name, bias=True, c_pad=None):
+        w = self.params[name + ".weight"]
+        if c_pad is not None and c_pad > w.shape[1]:
+            w = F.pad(w, (0, c_pad - w.shape[1]))
+        return conv1d(x, w, self.params[name + ".bias"] if bias else None)
+
+    def _block1d(self, p, x, maskf, lens, c_pad=None):
+        """Block1D (decoder.py:66-77): conv k3 of the masked input -> GroupNorm(8) -> Mish -> mask"""
+        w = pack_conv(self.params[p + "block.0.weight"], c_pad)
+        h, part = conv1d(x * maskf, w, self.params[p + "block.0.bias"], ops.conv_taps(3), want_gn=True)
+        return gn_mish(h, part, self.params[p + "block.1.weight"], self.params[p + "block.1.bias"], lens, self.GROUPS)
+
+    def _resnet(self, p, x, maskf, lens, temb, spk, c_pad=None):
+        """ResnetBlock1D (decoder.py:80-101) + SpeakerAdapter (decoder.py:23-45)"""
+        h = self._block1d(p + "block1.", x, maskf, lens, c_pad)
+        h = h + self._lin(F.mish(temb), p + "mlp.1").unsqueeze(1)
+        h = self._block1d(p + "block2.", h, maskf, lens)
+        out = h + conv1d(x * maskf, pack_conv(self.params[p + "res_conv.weight"], c_pad), self.params[p + "res_conv.bias"])
+        scale = self._lin(spk, p + "speaker_projection.W_scale")
+        shift = self._lin(spk, p + "speaker_projection.W_bias")
+        return row_ln(out, scale, shift)
+
+    def _tfm(self, p, x, lens):
+        """BasicTransformerBlock effective path (transformer.py:286-352): LN -> self-attention -> +x -> LN -> GEGLU FF
+        -> +x; dropout not applied (see module docstring)"""
+        P = self.params
+        n = row_ln(x, P[p + "norm1.weight"], P[p + "norm1.bias"])
+        wqkv = torch.cat([P[p + "attn1.to_q.weight"], P[p + "attn1.to_k.weight"], P[p + "attn1.to_v.weight"]], dim=0)
+        o = attention_core(conv1d(n, wqkv, None), lens, self.N_HEAD)
+        x = conv1d(o, P[p + "attn1.to_out.0.weight"], P[p + "attn1.to_out.0.bias"]) + x
+        n = row_ln(x, P[p + "norm3.weight"], P[p + "norm3.bias"])
+        a = geglu(conv1d(n, P[p + "ff.net.0.proj.weight"], P[p + "ff.net.0.proj.bias"]))
+        return conv1d(a, P[p + "ff.net.2.weight"], P[p + "ff.net.2.bias"]) + x
+
+    def forward(self, x, mask, mu, t, spks):
+        _require_cuda(x, "Estimator.forward")
+        P = self.params
+        B, _, L = x.shape
+        maskb = mask.reshape(B, L) > 0
+        h = torch.cat([x, mu], dim=1).transpose(1, 2)  # (B, L, 242) channels-last
+        cin = h.shape[-1]
+        cp = _rup(cin, 32)
+        h = F.pad(h, (0, cp - cin)).contiguous()
+        t = torch.as_tensor(t, device=x.device, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        s = sinusoidal_pos_emb(t, cin)
+        s = F.pad(s, (0, _rup(cin, 4) - cin))
+        temb = self._lin(F.silu(self._lin(s, "time_mlp.linear_1", c_pad=s.shape[1])), "time_mlp.linear_2")
+        spk = spks.to(torch.float32)
+
+        masks = [maskb]
+        hiddens = []
+        for i in range(self.n_down):
+            p = f"down_blocks.{i}."
+            m = masks[-1]
+            lens, mf = m.sum(1).to(torch.int32), m.unsqueeze(-1).to(torch.float32)
+            h = self._resnet(p + "0.", h, mf, lens, temb, spk, c_pad=cp if i == 0 else None)
+            h = self._tfm(p + "1.0.", h, lens)
+            hiddens.append(h)
+            if p + "2.conv.weight" in P:
+                h = conv1d(h * mf, pack_conv(P[p + "2.conv.weight"]), P[p + "2.conv.bias"], ops.conv_taps(3), stride=2)
+            else:
+                h = conv1d(h * mf, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3))
+            masks.append(m[:, ::2])
+        masks = masks[:-1]
+        m = masks[-1]
+        lens, mf = m.sum(1).to(torch.int32), m.unsqueeze(-1).to(torch.float32)
+        for i in range(self.n_mid):
+            p = f"mid_blocks.{i}."
+            h = self._resnet(p + "0.", h, mf, lens, temb, spk)
+            h = self._tfm(p + "1.0.", h, lens)
+        for i in range(self.n_up):
+            p = f"up_blocks.{i}."
+            m = masks.pop()
+            lens, mf = m.sum(1).to(torch.int32), m.unsqueeze(-1).to(torch.float32)
+            skip = hiddens.pop()
+            h = torch.cat([h[:, :skip.shape[1]], skip], dim=-1)
+            h = self._resnet(p + "0.", h, mf, lens, temb, spk)
+            h = self._tfm(p + "1.0.", h, lens)
+            if p + "2.conv.weight" in P:
+                # ConvTranspose1d(k 4, stride 2, padding 1): two output phases, each a 2-tap conv of the input
+                hm = h * mf
+                ys = []
+                for taps, wp in _convtranspose_phases(P[p + "2.conv.weight"], 2, 1):
+                    ys.append(conv1d(hm, wp, P[p + "2.conv.bias"], taps))
+                h = torch.stack(ys, dim=2).reshape(B, -1, ys[0].shape[-1])
+            else:
+                h = conv1d(h * mf, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3))
+        h = self._block1d("final_block.", h, mf, lens)
+        out = conv1d(h * mf, pack_conv(P["final_proj.weight"]), P["final_proj.bias"])
+        return (out * maskb.unsqueeze(-1).to(torch.float32)).transpose(1, 2)
+
+    __call__ = forward
+
+
+def _convtranspose_phases(w, stride, padding):
+    """differentiable twin of ops.convtranspose_phases: ConvTranspose1d weight (Ci, Co, k) -> per output phase
+    (input-row offsets, packed (Co, n_taps * Ci))"""
+    ci, co, k = w.shape
+    out = []
+    for r in range(stride):
+        taps, mats = [], []
+        j = -((r + padding) // stride)
+        while True:
+            kk = r + padding + j * stride
+            if kk >= k:
+                break
+            if kk >= 0:
+                taps.append(-j)
+                mats.append(w[:, :, kk].t())
+            j += 1
+        out.append((taps, torch.stack(mats, dim=1).reshape(co, len(taps) * ci)))
+    return out
+
+
+def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1e-4):
+    """CFM.compute_loss (flow_matching.py:95-133) with autograd through `estimator`.  `draws` = {"t": (B,1,1),
+    "z": like x1} fixes the random draws (parity tests); otherwise torch.rand / randn_like as in the reference."""
+    b = mu.shape[0]
+    if draws is None:
+        t = torch.rand([b, 1, 1], device=mu.device, dtype=mu.dtype)
+        z = torch.randn_like(x1)
+    else:
+        t, z = draws["t"].to(x1), draws["z"].to(x1)
+    y = (1 - (1 - sigma_min) * t) * z + t * x1
+    u = x1 - (1 - sigma_min) * z
+    den = estimator(y, mask, mu, t.reshape(-1), spks)
+    if mask_l is not None:
+        den = den * mask_l
+        u = u * mask_l
+    loss = F.mse_loss(den, u, reduction="sum")
+    denom = torch.sum(mask_l) if mask_l is not None else torch.sum(mask)
+    return loss / (denom * u.shape[1]), y
+
+
+# =====================================================================================================================
+#  gradient all-reduce (DDP replacement) and the optimizer
+# =====================================================================================================================
+class GradSync:
+    """All-reduce (mean) of `estimator.flat_grad` across the ranks, in buckets of ~`bucket_bytes`.
+
+    The reference wraps the model in DistributedDataParallel over NCCL (bin/ssc_train.py:353-358).  Here the flat
+    gradient buffer is cut into contiguous buckets; the parameters are laid out in forward order, so backward
+    completes the buckets from the last to the first, and a post-accumulate hook on every parameter launches its
+    bucket's asynchronous all-reduce the moment the bucket's last gradient has landed -- the RCCL transfers of the
+    late layers overlap the backward GEMMs of the early ones.  xGMI rings are per-link bound, so buckets are large
+    (default 64 MiB: 3 collectives for the 44 M-parameter estimator).  `finish()` waits and divides by the world size.
+    World size 1 (or no process group) makes every call a no-op."""
+
+    def __init__(self, estimator, bucket_bytes=64 << 20, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.est = estimator
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        per = max(1, bucket_bytes // 4)
+        total = estimator.flat.numel()
+        self.buckets = []  # (start, end)
+        lo = 0
+        names = list(estimator.spans)
+        for k in names:
+            off, n = estimator.spans[k]
+            end = off + _rup(n, 4)
+            if end - lo >= per or k == names[-1]:
+                self.buckets.append((lo, total if k == names[-1] else end))
+                lo = end
+        self.bucket_of = {}
+        self.count = [0] * len(self.buckets)
+        for k in names:
+            off, _ = estimator.spans[k]
+            bi = next(i for i, (s, e) in enumerate(self.buckets) if s <= off < e)
+            self.bucket_of[k] = bi
+            self.count[bi] += 1
+        self._left = list(self.count)
+        self._work = []
+        self._hooks = []
+        if self.world > 1:
+            for k, p in estimator.params.items():
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[k])))
+
+    def _make_hook(self, bi):
+        def hook(_):
+            self._left[bi] -= 1
+            if self._left[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        s, e = self.buckets[bi]
+        self._work.append(self.dist.all_reduce(self.est.flat_grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+
+    def finish(self):
+        """call after backward(): launches whatever the hooks did not (unused parameters), waits, averages"""
+        if self.world == 1:
+            return
+        for bi, left in enumerate(self._left):
+            if left > 0:
+                self._launch(bi)
+        for w in self._work:
+            w.wait()
+        self._work = []
+        self._left = list(self.count)
+        self.est.flat_grad.div_(self.world)
+
+
+class AdamW:
+    """clip_grad_norm_(max_norm) + torch.optim.AdamW (trainers/ssc.py:90-95; conf/serenade.yaml:62-65: lr 8e-4,
+    grad_norm 1.0, torch defaults betas (0.9, 0.999), eps 1e-8, weight_decay 0.01) as ONE kernel over the flat buffers."""
+
+    def __init__(self, estimator, lr=8e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0):
+        self.est = estimator
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.m = torch.zeros_like(estimator.flat)
+        self.v = torch.zeros_like(estimator.flat)
+        self.steps = 0
+
+    def step(self):
+        """returns the gradient norm before clipping (what clip_grad_norm_ returns)"""
+        _require_cuda(self.est.flat, "AdamW.step")
+        g = self.est.flat_grad
+        norm = float(torch.linalg.vector_norm(g, dtype=torch.float64))
+        scale = 1.0
+        if self.max_norm and self.max_norm > 0:
+            scale = min(1.0, self.max_norm / (norm + 1e-6))
+        self.steps += 1
+        with torch.no_grad():
+            _call("srn_adamw", self.est.flat, g, self.m, self.v, g.numel(), self.lr, self.betas[0], self.betas[1],
+                  self.eps, self.wd, self.steps, scale)
+        return norm

@@ -309,6 +309,79 @@ def emul_call(name, a):
         sc = torch.einsum("bhd,thd->bht", q.view(B, nh, dk), k.view(n_tok, nh, dk)) / math.sqrt(dk)
         ctx = torch.einsum("bht,thd->bhd", torch.softmax(sc, -1), v.view(n_tok, nh, dk)).reshape(B, Fd)
         _v(out, B * Fd).reshape(B, Fd)[:] = ctx @ wo.t() + bo
+    elif name == "srn_rowln_fwd":
+        x, m, m_bs, a_, a_bs, y, B, T, C, eps = a
+        xv = _v(x, B * T * C).reshape(B, T, C)
+        mv = _v(m).reshape(-1)[: (B if m_bs else 1) * C].reshape(-1, C)
+        av = _v(a_).reshape(-1)[: (B if a_bs else 1) * C].reshape(-1, C)
+        _v(y, B * T * C).reshape(B, T, C)[:] = F.layer_norm(xv, (C,), None, None, eps) * mv.unsqueeze(1) + av.unsqueeze(1)
+    elif name == "srn_rowln_bwd":
+        x, dy, m, m_bs, dx, part, B, T, C, eps = a
+        xv = _v(x, B * T * C).reshape(B, T, C).clone().requires_grad_(True)
+        dv = _v(dy, B * T * C).reshape(B, T, C)
+        mv = _v(m).reshape(-1)[: (B if m_bs else 1) * C].reshape(-1, C)
+        with torch.enable_grad():
+            xh = F.layer_norm(xv, (C,), None, None, eps)
+            (xh * mv.unsqueeze(1)).backward(dv)
+        _v(dx, B * T * C).reshape(B, T, C)[:] = xv.grad
+        nch = (T + 31) // 32
+        pv = _v(part, B * nch * 2 * C).reshape(B, nch, 2, C)
+        xh = xh.detach()
+        for c in range(nch):
+            sl = slice(c * 32, min(T, (c + 1) * 32))
+            pv[:, c, 0] = (dv[:, sl] * xh[:, sl]).sum(1)
+            pv[:, c, 1] = dv[:, sl].sum(1)
+    elif name in ("srn_gn_mish_bwd_partial", "srn_gn_mish_bwd_apply"):
+        if name.endswith("partial"):
+            h, dy, mean, rstd, gamma, beta, lens, out, B, T, C, G = a
+        else:
+            h, dy, mean, rstd, gamma, beta, gsum, lens, out, B, T, C, G = a
+        hv, dv = (_v(t, B * T * C).reshape(B, T, C) for t in (h, dy))
+        mu = _v(mean, B * G).reshape(B, 1, G).repeat_interleave(C // G, dim=2)
+        rs = _v(rstd, B * G).reshape(B, 1, G).repeat_interleave(C // G, dim=2)
+        xh = (hv - mu) * rs
+        gpre = (xh * gamma + beta).clone().requires_grad_(True)
+        with torch.enable_grad():
+            F.mish(gpre).backward(torch.ones_like(gpre))
+        valid = (torch.arange(T)[None, :, None] < (_v(lens, B).reshape(B, 1, 1) if lens is not None else T)).float()
+        dg = dv * gpre.grad * valid
+        if name.endswith("partial"):
+            nch = (T + 31) // 32
+            pv = _v(out, B * nch * 2 * C).reshape(B, nch, 2, C)
+            for c in range(nch):
+                sl = slice(c * 32, min(T, (c + 1) * 32))
+                pv[:, c, 0] = dg[:, sl].sum(1)
+                pv[:, c, 1] = (dg[:, sl] * xh[:, sl]).sum(1)
+        else:
+            n = float(T * (C // G))
+            gs = _v(gsum, B * G * 2).reshape(B, G, 2)
+            A = gs[:, :, 0].reshape(B, 1, G).repeat_interleave(C // G, dim=2) / n
+            Bq = gs[:, :, 1].reshape(B, 1, G).repeat_interleave(C // G, dim=2) / n
+            _v(out, B * T * C).reshape(B, T, C)[:] = rs * (dg * gamma - A - xh * Bq)
+    elif name == "srn_softmax_bwd":
+        pm, dp, rows, L, ld, scale = a
+        pv = _v(pm, rows * ld).reshape(rows, ld)[:, :L]
+        dv = _v(dp, rows * ld).reshape(rows, ld)
+        g = dv[:, :L].clone()
+        dv[:, :L] = scale * pv * (g - (g * pv).sum(-1, keepdim=True))
+    elif name == "srn_geglu_fwd":
+        hg, out, rows, inner = a
+        hv = _v(hg, rows * 2 * inner).reshape(rows, 2 * inner)
+        _v(out, rows * inner).reshape(rows, inner)[:] = hv[:, :inner] * F.gelu(hv[:, inner:])
+    elif name == "srn_geglu_bwd":
+        hg, da, dhg, rows, inner = a
+        hv = _v(hg, rows * 2 * inner).reshape(rows, 2 * inner).clone().requires_grad_(True)
+        with torch.enable_grad():
+            (hv[:, :inner] * F.gelu(hv[:, inner:])).backward(_v(da, rows * inner).reshape(rows, inner))
+        _v(dhg, rows * 2 * inner).reshape(rows, 2 * inner)[:] = hv.grad
+    elif name == "srn_adamw":
+        pp, g, m, v, n, lr, b1, b2, eps, wd, step, gscale = a
+        pv, gv, mv, vv = (_v(t, n) for t in (pp, g, m, v))
+        gi = gv * gscale
+        pv.mul_(1 - lr * wd)
+        mv.mul_(b1).add_(gi, alpha=1 - b1)
+        vv.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        pv.addcdiv_(mv / (1 - b1 ** step), (vv / (1 - b2 ** step)).sqrt() + eps, value=-lr)
     else:
         raise NotImplementedError(name)
 
@@ -334,8 +407,8 @@ class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
     def __enter__(self):
-        from serenade_amd import features, sifigan
-        self._mods = (models, vocoder, sifigan, features)
+        from serenade_amd import features, sifigan, training
+        self._mods = (models, vocoder, sifigan, features, training)
         self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods],
                        ops.ResUnitOp.__call__)
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)

@@ -222,6 +222,74 @@ def euler20_case():
     npz("euler20_L57", lens=np.array(lens), mu=mu, spk=spk, z=z, x1=keep[1], x10=keep[10], out=final)
 
 
+TRAIN_FULL = ["final_proj.weight", "final_proj.bias", "final_block.block.1.weight", "time_mlp.linear_1.bias",
+              "down_blocks.0.0.block1.block.1.weight", "down_blocks.0.0.block1.block.1.bias",
+              "down_blocks.0.0.speaker_projection.W_scale.bias", "mid_blocks.1.0.mlp.1.bias",
+              "mid_blocks.0.1.0.norm1.weight", "up_blocks.1.1.0.norm3.bias", "up_blocks.0.1.0.attn1.to_out.0.bias"]
+TRAIN_ROWS = ["down_blocks.0.0.block1.block.0.weight", "down_blocks.0.0.res_conv.weight", "down_blocks.0.2.conv.weight",
+              "down_blocks.1.1.0.attn1.to_q.weight", "mid_blocks.0.1.0.attn1.to_k.weight",
+              "mid_blocks.1.1.0.attn1.to_v.weight", "up_blocks.0.1.0.ff.net.0.proj.weight",
+              "up_blocks.0.1.0.ff.net.2.weight", "up_blocks.0.2.conv.weight", "up_blocks.1.0.block1.block.0.weight",
+              "time_mlp.linear_2.weight", "mid_blocks.0.0.speaker_projection.W_bias.weight"]
+
+
+def train_grads_case():
+    """f4: the reference's own CFM.compute_loss (flow_matching.py:95-133) + loss.backward() on explicit inputs, in
+    eval mode (dropout off, as the HIP training step), odd padded length.  Stored: the draws it made, the loss, the
+    gradient of a dozen whole parameters, the first 4 rows of a dozen big ones, d mu, d spks and the global gradient
+    norm over all 192 estimator parameters (what clip_grad_norm_ would report).
+
+        PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py train
+    """
+    torch.set_grad_enabled(True)
+    model = Serenade(**SERENADE_PARAMS).eval()
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    cfm = model.cfm_decoder
+    rng = np.random.default_rng(780)
+    L, lens = 45, [45, 31, 38]
+    B = len(lens)
+    mask = make_non_pad_mask(lens).unsqueeze(1).float()
+    mask_l = mask.clone()
+    mask_l[:, :, :9] = 0
+    mask_l[:, :, 27:] = 0
+    x1 = rnd(rng, B, 80, L) * mask_l
+    mu = (rnd(rng, B, 162, L) * mask).requires_grad_(True)
+    spk = rnd(rng, B, 256).requires_grad_(True)
+    draws = {}
+    o_rand, o_randn_like = torch.rand, torch.randn_like
+
+    def rand(*a, **k):
+        draws["t"] = o_rand(*a, **k)
+        return draws["t"]
+
+    def randn_like(t, **k):
+        draws["z"] = o_randn_like(t, **k)
+        return draws["z"]
+
+    torch.manual_seed(11)
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        loss, _ = cfm.compute_loss(x1, mask, mu, spk, mask_l)
+    finally:
+        torch.rand, torch.randn_like = o_rand, o_randn_like
+    loss.backward()
+    g = {k: p.grad for k, p in cfm.estimator.named_parameters()}
+    assert len(g) == 192 and all(v is not None for v in g.values())
+    total = torch.sqrt(sum((v.double() ** 2).sum() for v in g.values()))
+    out = dict(lens=np.array(lens), x1=x1, mu=mu, spk=spk, mask_l=mask_l, t=draws["t"], z=draws["z"], loss=loss,
+               grad_norm=total, dmu=mu.grad, dspk=spk.grad)
+    for k in TRAIN_FULL:
+        out["g:" + k] = g[k]
+    for k in TRAIN_ROWS:
+        out["r:" + k] = g[k][:4]
+    npz("train_grads_L45", **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "train":
+    train_grads_case()
+    sys.exit(0)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "euler20":
     euler20_case()
     sys.exit(0)

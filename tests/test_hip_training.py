@@ -1,0 +1,189 @@
+"""SURVEY 8 f4 on the GPU: the estimator's training step (serenade_amd/training.py over libserenade_hip.so).
+
+  * every backward kernel of csrc/train.hip against torch autograd of the op it differentiates;
+  * loss + gradients of all 192 estimator parameters, d mu, d spks against the REFERENCE's own
+    CFM.compute_loss + backward() (tests/golden/train_grads_L45.npz) and, at a larger ragged batch, against autograd
+    through the CPU oracle;
+  * bit-reproducibility, and three clipped AdamW steps against torch.optim.AdamW on the oracle's gradients.
+Tolerances: gradients 2e-4 of each tensor's max (fp32 sums in a different order; the forward gate is 1e-5)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import serenade_oracle as O
+from serenade_amd import _lib, training
+from tests._weights import serenade_weights, sub
+from tests.test_training_emulated import _case, _golden_case, _oracle_grads, check_against_reference_gradients, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu-marked tests need an MI355X"
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return sub(serenade_weights(), "cfm_decoder.estimator.")
+
+
+def _leaf(t, dev):
+    return t.to(dev).requires_grad_(True)
+
+
+def test_conv_backward(dev):
+    """dgrad through srn_conv_gemm (transposed weights; stride 2 by output parity), wgrad / dbias, vs F.conv1d"""
+    g = torch.Generator().manual_seed(1)
+    for (B, T, C, N, k, stride) in [(2, 37, 64, 96, 3, 1), (3, 50, 32, 64, 3, 2), (2, 41, 128, 32, 3, 2),
+                                    (1, 9, 244, 64, 1, 1), (2, 20, 80, 52, 1, 1)]:
+        x = torch.randn(B, T, C, generator=g)
+        w = torch.randn(N, C, k, generator=g) / math.sqrt(C * k)
+        b = torch.randn(N, generator=g)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = F.conv1d(xr.transpose(1, 2), wr, br, stride=stride, padding=(k - 1) // 2).transpose(1, 2)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy)
+        xd, wd, bd = _leaf(x, dev), _leaf(w, dev), _leaf(b, dev)
+        taps = [j - (k - 1) // 2 for j in range(k)]
+        y = training.conv1d(xd, training.pack_conv(wd), bd, taps, stride=stride)
+        assert y.shape == ref.shape and rel(y.detach().cpu(), ref.detach()) < 1e-5
+        y.backward(dy.to(dev))
+        for a, r in ((xd, xr), (wd, wr), (bd, br)):
+            assert rel(a.grad.cpu(), r.grad) < 1e-5, (B, T, C, N, k, stride)
+
+
+def test_gn_mish_backward(dev):
+    g = torch.Generator().manual_seed(2)
+    B, T, C = 3, 45, 256
+    lens = torch.tensor([45, 31, 38])
+    x = torch.randn(B, T, 64, generator=g)
+    w = torch.randn(C, 64 * 3, generator=g) / 14
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    maskf = (torch.arange(T)[None] < lens[:, None]).float().unsqueeze(-1)
+    dy = torch.randn(B, T, C, generator=g)
+    xr, wr, gr, br = (t.clone().requires_grad_(True) for t in (x, w, gam, bet))
+    h = F.conv1d((xr * maskf).transpose(1, 2), wr.view(C, 3, 64).permute(0, 2, 1), None, padding=1)
+    ref = (F.mish(F.group_norm(h, 8, gr, br, 1e-5)) * maskf.transpose(1, 2)).transpose(1, 2)
+    ref.backward(dy)
+    xd, wd, gd, bd = (_leaf(t, dev) for t in (x, w, gam, bet))
+    hh, part = training.conv1d(xd * maskf.to(dev), wd, None, [-1, 0, 1], want_gn=True)
+    y = training.gn_mish(hh, part, gd, bd, lens.to(dev).to(torch.int32))
+    assert rel(y.detach().cpu(), ref.detach()) < 1e-5
+    y.backward(dy.to(dev))
+    for a, r in ((xd, xr), (wd, wr), (gd, gr), (bd, br)):
+        assert rel(a.grad.cpu(), r.grad) < 2e-5
+
+
+def test_row_layernorm_backward(dev):
+    g = torch.Generator().manual_seed(3)
+    B, T, C = 3, 70, 512
+    x, dy = torch.randn(B, T, C, generator=g) * 2 + 0.3, torch.randn(B, T, C, generator=g)
+    for per_b in (False, True):
+        m = torch.randn((B, C) if per_b else (C,), generator=g)
+        a = torch.randn((B, C) if per_b else (C,), generator=g)
+        xr, mr, ar = (t.clone().requires_grad_(True) for t in (x, m, a))
+        xh = F.layer_norm(xr, (C,), None, None, 1e-5)
+        ref = xh * (mr.unsqueeze(1) if per_b else mr) + (ar.unsqueeze(1) if per_b else ar)
+        ref.backward(dy)
+        xd, md, ad = (_leaf(t, dev) for t in (x, m, a))
+        y = training.row_ln(xd, md, ad)
+        assert rel(y.detach().cpu(), ref.detach()) < 1e-5
+        y.backward(dy.to(dev))
+        for u, r in ((xd, xr), (md, mr), (ad, ar)):
+            assert rel(u.grad.cpu(), r.grad) < 2e-5, per_b
+
+
+def test_attention_core_backward(dev):
+    g = torch.Generator().manual_seed(4)
+    B, L, H, hd = 2, 45, 4, 64
+    lens = torch.tensor([45, 30])
+    qkv = torch.randn(B, L, 3 * H * hd, generator=g)
+    do = torch.randn(B, L, H * hd, generator=g)
+    r = qkv.clone().requires_grad_(True)
+    q, k, v = (t.view(B, L, H, hd).transpose(1, 2) for t in r.chunk(3, dim=-1))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    s = s.masked_fill(~(torch.arange(L)[None] < lens[:, None]).view(B, 1, 1, L), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, H * hd)
+    ref.backward(do)
+    d = _leaf(qkv, dev)
+    o = training.attention_core(d, lens.to(dev).to(torch.int32), H)
+    assert rel(o.detach().cpu(), ref.detach()) < 1e-5
+    o.backward(do.to(dev))
+    assert rel(d.grad.cpu(), r.grad) < 2e-5
+
+
+def test_geglu_backward(dev):
+    g = torch.Generator().manual_seed(5)
+    hg, da = torch.randn(3, 17, 256, generator=g) * 2, torch.randn(3, 17, 128, generator=g)
+    r = hg.clone().requires_grad_(True)
+    h, gate = r.chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    ref.backward(da)
+    d = _leaf(hg, dev)
+    a = training.geglu(d)
+    assert rel(a.detach().cpu(), ref.detach()) < 1e-6
+    a.backward(da.to(dev))
+    assert rel(d.grad.cpu(), r.grad) < 1e-5
+
+
+def _run(est, case, dev):
+    x1, mask, mu, spk, mask_l, t, z = (c.to(dev) for c in case)
+    mu_r, spk_r = mu.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    est.zero_grad()
+    loss, _ = training.cfm_loss(est, x1, mask, mu_r, spk_r, mask_l, draws={"t": t, "z": z})
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().cpu(), {k: v.grad.detach().cpu().clone() for k, v in est.params.items()}, mu_r.grad.cpu(), spk_r.grad.cpu()
+
+
+def test_gradients_match_the_reference(dev, weights, golden):
+    """the reference's own compute_loss + backward() (3 utterances, L = 45 odd, padded, infill segment 9..27)"""
+    g = golden("train_grads_L45")
+    est = training.Estimator(weights, dev)
+    loss, grads, dmu, dspk = _run(est, _golden_case(g), dev)
+    check_against_reference_gradients(g, loss, grads, dmu, dspk)
+    again = _run(est, _golden_case(g), dev)
+    assert torch.equal(again[0], loss) and all(torch.equal(again[1][k], grads[k]) for k in grads)  # bit-reproducible
+
+
+def test_gradients_match_oracle_autograd_larger_batch(dev, weights):
+    case = _case(B=4, L=203, lens=(203, 150, 97, 180), seed=9)
+    ref_loss, ref_g, ref_dmu, ref_dspk = _oracle_grads(weights, case)
+    est = training.Estimator(weights, dev)
+    loss, grads, dmu, dspk = _run(est, case, dev)
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    worst = max((rel(grads[k], ref_g[k]), k) for k in ref_g)
+    assert worst[0] < 2e-4, worst
+    assert rel(dmu, ref_dmu) < 2e-4 and rel(dspk, ref_dspk) < 2e-4
+
+
+def test_three_training_steps_match_torch_adamw(dev, weights):
+    """loss.backward -> clip_grad_norm_(1.0) -> AdamW(lr 8e-4), three times, against torch on the oracle's autograd"""
+    case = _case(B=2, L=40, lens=(40, 29), seed=21)
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in weights.items()}
+    opt_ref = torch.optim.AdamW(ref.values(), lr=8e-4)
+    est = training.Estimator(weights, dev)
+    opt = training.AdamW(est, lr=8e-4, max_grad_norm=1.0)
+    x1, mask, mu, spk, mask_l, t, z = case
+    losses = []
+    for step in range(3):
+        opt_ref.zero_grad()
+        l_ref, _ = O.cfm_compute_loss(ref, x1, mask, mu, spk, mask_l, t, z)
+        l_ref.backward()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref.values(), 1.0)
+        opt_ref.step()
+        loss, _, _, _ = _run(est, case, dev)
+        n = opt.step()
+        assert abs(loss.item() - l_ref.item()) < 2e-4 * abs(l_ref.item()), step
+        assert abs(n - float(n_ref)) < 1e-3 * float(n_ref), step
+        losses.append(loss.item())
+    assert losses[2] < losses[0]
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size, so compare the UPDATES
+    worst = max((rel(est.params[k].detach().cpu() - weights[k], ref[k].detach() - weights[k]), k) for k in weights)
+    assert worst[0] < 5e-2, worst

@@ -76,3 +76,49 @@ def test_single_process_is_identity():
     w = torch.randn(2, 10)
     waves, ns = gather_waveforms(w)
     assert waves[0] is w and ns[0].tolist() == [10, 10]
+
+
+# ---- f4: the DDP replacement of the training step (serenade_amd/training.py GradSync) ------------------------------
+def _grad_worker(rank, world, port, q):
+    from serenade_amd import training
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    sd = {f"p{i}": torch.randn(s, generator=g) for i, s in enumerate([(7, 5), (33,), (64, 9), (3,), (128, 4), (10,)])}
+    est = training.Estimator(sd, torch.device("cpu"))
+    sync = training.GradSync(est, bucket_bytes=2048)  # several buckets, the last ones finish first in backward
+    assert len(sync.buckets) >= 3 and sync.buckets[0][0] == 0 and sync.buckets[-1][1] == est.flat.numel()
+    for step in range(2):  # twice: the bucket counters re-arm
+        est.zero_grad()
+        coef = {k: torch.randn(v.shape, generator=torch.Generator().manual_seed(100 * rank + i + 7 * step))
+                for i, (k, v) in enumerate(sd.items())}
+        used = [k for k in sd if not (step == 1 and k == "p3")]  # step 1: one parameter gets no gradient at all
+        loss = sum((est.params[k] * coef[k]).sum() for k in used)
+        loss.backward()
+        sync.finish()
+        expect = {}
+        for i, k in enumerate(sd):
+            both = [torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(100 * r + i + 7 * step))
+                    for r in range(world)]
+            expect[k] = sum(both) / world if k in used else torch.zeros_like(sd[k])
+        for k in sd:
+            assert torch.allclose(est.params[k].grad, expect[k], atol=1e-6), (step, k)
+    if rank == 0:
+        q.put(len(sync.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_buckets_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n_buckets = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert n_buckets >= 3

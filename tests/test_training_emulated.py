@@ -1,0 +1,119 @@
+"""SURVEY 8 f4 on the CPU: the estimator's training step (serenade_amd/training.py) through the kernel emulator,
+against autograd through the CPU oracle's `cfm_compute_loss` (flow_matching.py:95-133 over decoder.py) on the same
+weights, inputs and random draws: the loss value and all 192 parameter gradients, d mu and d spks; then one clipped
+AdamW step against torch.optim.AdamW + clip_grad_norm_ (trainers/ssc.py:86-96)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import serenade_oracle as O
+from serenade_amd import training
+from tests import _emulator
+from tests._weights import serenade_weights, sub
+
+
+def _case(B=2, L=24, lens=(24, 17), seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(B, 80, L, generator=g)
+    mu = torch.randn(B, 162, L, generator=g)
+    spk = torch.randn(B, 256, generator=g)
+    mask = O.make_non_pad_mask(list(lens)).unsqueeze(1).float()
+    mask_l = mask.clone()
+    mask_l[:, :, :5] = 0
+    mask_l[:, :, 14:] = 0
+    t = torch.rand(B, 1, 1, generator=g)
+    z = torch.randn(B, 80, L, generator=g)
+    return x1 * mask, mask, mu * mask, spk, mask_l, t, z
+
+
+def _oracle_grads(w, case):
+    x1, mask, mu, spk, mask_l, t, z = case
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    mu_r, spk_r = mu.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    loss, _ = O.cfm_compute_loss(wr, x1, mask, mu_r, spk_r, mask_l, t, z)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in wr.items()}, mu_r.grad, spk_r.grad
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_estimator_gradients_match_oracle_autograd():
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    case = _case()
+    ref_loss, ref_g, ref_dmu, ref_dspk = _oracle_grads(w, case)
+    x1, mask, mu, spk, mask_l, t, z = case
+    with _emulator.installed():
+        est = training.Estimator(w, torch.device("cpu"))
+        mu_r, spk_r = mu.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+        loss, _ = training.cfm_loss(est, x1, mask, mu_r, spk_r, mask_l, draws={"t": t, "z": z})
+        loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5 * abs(ref_loss.item())
+    assert set(est.params) == set(ref_g)
+    worst = max((rel(est.params[k].grad, ref_g[k]), k) for k in ref_g)
+    assert worst[0] < 2e-4, worst
+    assert rel(mu_r.grad, ref_dmu) < 2e-4 and rel(spk_r.grad, ref_dspk) < 2e-4
+    # the gradients live in the flat buffer the optimizer and the all-reduce work on
+    off, n = est.spans["final_proj.weight"]
+    assert torch.equal(est.flat_grad[off:off + n], est.params["final_proj.weight"].grad.reshape(-1))
+
+
+def test_clipped_adamw_step_matches_torch():
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    w = {k: w[k] for k in list(w)[:12]}  # a dozen tensors are enough for the update rule
+    g = torch.Generator().manual_seed(0)
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in w.items()}
+    opt_ref = torch.optim.AdamW(ref.values(), lr=8e-4)
+    with _emulator.installed():
+        est = training.Estimator(w, torch.device("cpu"))
+        opt = training.AdamW(est, lr=8e-4, max_grad_norm=1.0)
+        for _ in range(3):
+            for k in w:
+                gk = torch.randn(w[k].shape, generator=g) * 3.0
+                est.params[k].grad.copy_(gk)
+                ref[k].grad = gk.clone()
+            n_ref = torch.nn.utils.clip_grad_norm_(ref.values(), 1.0)
+            opt_ref.step()
+            n = opt.step()
+            assert abs(n - float(n_ref)) < 1e-4 * float(n_ref)
+    for k in w:
+        assert rel(est.params[k], ref[k]) < 1e-6, k
+
+
+def _golden_case(g):
+    t = lambda k: torch.from_numpy(np.asarray(g[k]))
+    mask = O.make_non_pad_mask(g["lens"].tolist()).unsqueeze(1).float()
+    return t("x1"), mask, t("mu"), t("spk"), t("mask_l"), t("t"), t("z")
+
+
+def check_against_reference_gradients(g, loss, grads, dmu, dspk, tol=2e-4):
+    """`g` = tests/golden/train_grads_L45.npz: the reference's own CFM.compute_loss + backward()"""
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for key in g:
+        if key.startswith("g:"):
+            assert rel(grads[key[2:]], torch.from_numpy(g[key])) < tol, key
+        elif key.startswith("r:"):
+            assert rel(grads[key[2:]][:4], torch.from_numpy(g[key])) < tol, key
+    total = math.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    assert abs(total - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
+    assert rel(dmu, torch.from_numpy(g["dmu"])) < tol and rel(dspk, torch.from_numpy(g["dspk"])) < tol
+
+
+def test_reference_gradient_fixture(golden):
+    """the reference's gradients pin (a) autograd through the oracle and (b) the HIP training step's host logic"""
+    g = golden("train_grads_L45")
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    case = _golden_case(g)
+    loss, grads, dmu, dspk = _oracle_grads(w, case)
+    check_against_reference_gradients(g, loss, grads, dmu, dspk)
+    x1, mask, mu, spk, mask_l, t, z = case
+    with _emulator.installed():
+        est = training.Estimator(w, torch.device("cpu"))
+        mu_r, spk_r = mu.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+        loss, _ = training.cfm_loss(est, x1, mask, mu_r, spk_r, mask_l, draws={"t": t, "z": z})
+        loss.backward()
+    check_against_reference_gradients(g, loss.detach(), {k: v.grad for k, v in est.params.items()}, mu_r.grad,
+                                      spk_r.grad)
