@@ -50,6 +50,53 @@ def algorithmic_flops(B, T, T_ref, n):
     return B * (n * (81.3e6 * L + 24576.0 * L * L) + 11.32e6 * (T + T_ref) + 499e6 * T)
 
 
+def train_step_bench(dev, sd, B=4, L=1024, steps=3):
+    """SURVEY 8 f4, a secondary line: one training step of the flow-matching estimator (forward with saved
+    activations, backward, clip + AdamW) at the reference's per-GPU batch (conf/serenade.yaml:52 batch_size 4) on
+    L = 1024 frames, exact-fp32 contraction.  FLOPs = 3 x the estimator's forward."""
+    from serenade_amd import training
+    est = training.Estimator({k[len("cfm_decoder.estimator."):]: v for k, v in sd.items()
+                              if k.startswith("cfm_decoder.estimator.")}, dev)
+    opt = training.AdamW(est)
+    sync = training.GradSync(est)
+    g = torch.Generator().manual_seed(4321)
+    lens = torch.tensor([L - 37 * i for i in range(B)])
+    mask = (torch.arange(L)[None] < lens[:, None]).float().unsqueeze(1).to(dev)
+    mask_l = mask.clone()
+    mask_l[:, :, : L // 4] = 0
+    mask_l[:, :, L // 2:] = 0
+    x1 = torch.randn(B, 80, L, generator=g).to(dev) * mask_l
+    mu = torch.randn(B, 162, L, generator=g).to(dev) * mask
+    spk = torch.randn(B, 256, generator=g).to(dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phases = {"forward_ms": 0.0, "backward_ms": 0.0, "optimizer_ms": 0.0}
+    loss0 = loss = None
+    for it in range(steps + 1):  # one warm-up
+        e = [ev() for _ in range(4)]
+        est.zero_grad()
+        e[0].record()
+        loss, _ = training.cfm_loss(est, x1, mask, mu, spk, mask_l)
+        e[1].record()
+        loss.backward()
+        sync.finish()
+        e[2].record()
+        opt.step()
+        e[3].record()
+        torch.cuda.synchronize()
+        if it == 0:
+            loss0 = float(loss)
+            t0 = time.perf_counter()
+        else:
+            for k, (a, b) in zip(phases, ((0, 1), (1, 2), (2, 3))):
+                phases[k] += e[a].elapsed_time(e[b]) / steps
+    dt = (time.perf_counter() - t0) / steps
+    fl = 3.0 * B * (81.3e6 * L + 24576.0 * L * L)
+    return {"workload": f"estimator training step, B={B} x L={L} (ragged lengths), exact fp32, AdamW lr 8e-4 clip 1.0",
+            "ms_per_step": dt * 1e3, "frames_per_s": B * L / dt, "tflops": fl / dt / 1e12,
+            "parameters": int(sum(v.numel() for v in est.params.values())), **phases,
+            "loss_first": loss0, "loss_last": float(loss), "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2**30}
+
+
 def build_id():
     """hash of the kernel sources + C ABI the loaded library was built from (profiles/ records carry the same id)"""
     h = hashlib.sha1()
@@ -195,6 +242,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the north-star size sweep (profiling runs)")
+    ap.add_argument("--no-train", action="store_true", help="skip the estimator training-step line (SURVEY 8 f4)")
     ap.add_argument("--modes", default="fp32,bf16x6,bf16x3", help="contraction modes to time; the first is the "
                                                                   "headline (profiling runs pass one)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the "
@@ -368,6 +416,9 @@ def main():
         out[MODE_KEY[m]] = results[m]
     if rank == 0 and world == 1 and not args.no_sweep:
         out["sweep"] = sweep()
+    if rank == 0 and world == 1 and not args.no_train:
+        serenade_amd.set_precision(modes[0])
+        out["train_step"] = train_step_bench(dev, sd)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, gsd)
     if rank == 0:

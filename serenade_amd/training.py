@@ -110,16 +110,25 @@ class _Conv(torch.autograd.Function):
                     _launch_conv(dy, wsel, None, dx, [(ph - taps[j]) // stride for j in sel], B, T_out, rows, N, C,
                                  out_t_stride=stride, out_t_off=ph, ld_out=C, out_bs=T * C)
         if ctx.needs_input_grad[1]:
-            # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- contraction over time: rocBLAS
-            lo, hi = min(min(taps), 0), max(max(taps), 0)
-            need = (T_out - 1) * stride + hi + 1
-            xp = F.pad(x, (0, 0, -lo, max(0, need - T)))
-            dyt = dy.transpose(1, 2)  # (B, N, T_out)
-            mats = []
-            for o in taps:
-                xs = xp[:, o - lo: o - lo + (T_out - 1) * stride + 1: stride]  # (B, T_out, C) view
-                mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
-            dw = torch.stack(mats, dim=1).reshape(N, nt * C)
+            # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- contraction over time: rocBLAS.
+            # Stride 1: one transposed-A GEMM per tap over the batch-flattened rows; both operands carry P zero rows
+            # between batch items, so a tap's shift never pairs rows of different items.
+            if stride == 1:
+                P = max(abs(o) for o in taps)
+                xp = F.pad(x, (0, 0, P, P)).reshape(-1, C) if P else x.reshape(-1, C)
+                dyp = F.pad(dy, (0, 0, P, P)).reshape(-1, N) if P else dy.reshape(-1, N)
+                n = xp.shape[0]
+                mats = [torch.matmul(dyp[P:n - P].t(), xp[P + o:n - P + o]) for o in taps]
+            else:
+                lo, hi = min(min(taps), 0), max(max(taps), 0)
+                need = (T_out - 1) * stride + hi + 1
+                xp = F.pad(x, (0, 0, -lo, max(0, need - T)))
+                dyt = dy.transpose(1, 2)  # (B, N, T_out)
+                mats = []
+                for o in taps:
+                    xs = xp[:, o - lo: o - lo + (T_out - 1) * stride + 1: stride]  # (B, T_out, C) view
+                    mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
+            dw = torch.stack(mats, dim=1).reshape(N, nt * C) if nt > 1 else mats[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 1))
         return dx, dw, db, None, None, None, None

@@ -190,7 +190,7 @@ def test_rccl_group_of_one(dev, precision):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-sweep", "--force-dist", "--batch", "2", "--frames", "64",
+                        "--no-cpu-baseline", "--no-sweep", "--no-train", "--force-dist", "--batch", "2", "--frames", "64",
                         "--ref-frames", "32", "--modes", "fp32"], env=env, capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
