@@ -59,6 +59,7 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
                               if k.startswith("cfm_decoder.estimator.")}, dev)
     opt = training.AdamW(est)
     sync = training.GradSync(est)
+    torch.cuda.reset_peak_memory_stats(dev)
     g = torch.Generator().manual_seed(4321)
     lens = torch.tensor([L - 37 * i for i in range(B)])
     mask = (torch.arange(L)[None] < lens[:, None]).float().unsqueeze(1).to(dev)
