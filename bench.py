@@ -51,32 +51,28 @@ def algorithmic_flops(B, T, T_ref, n):
 
 
 def train_step_bench(dev, sd, B=4, L=1024, steps=3):
-    """SURVEY 8 f4, a secondary line: one training step of the flow-matching estimator (forward with saved
-    activations, backward, clip + AdamW) at the reference's per-GPU batch (conf/serenade.yaml:52 batch_size 4) on
-    L = 1024 frames, exact-fp32 contraction.  FLOPs = 3 x the estimator's forward."""
+    """SURVEY 8 f4, a secondary line: one training step of the whole model as the reference's trainer runs it
+    (trainers/ssc.py:57-96: Serenade.forward -> cfm_loss + prior_loss -> backward -> clip_grad_norm_(1.0) -> AdamW
+    lr 8e-4; dropout 0.05) at its per-GPU batch (conf/serenade.yaml:52 batch_size 4) on L = 1024 frames, exact-fp32
+    contraction.  FLOPs = 3 x the forward of estimator + encoder (the GST's 0.8 GFLOP is not counted)."""
     from serenade_amd import training
-    est = training.Estimator({k[len("cfm_decoder.estimator."):]: v for k, v in sd.items()
-                              if k.startswith("cfm_decoder.estimator.")}, dev)
-    opt = training.AdamW(est)
-    sync = training.GradSync(est)
+    model = training.TrainSerenade(sd, dev, dropout=0.05)
+    opt = training.AdamW(model)
+    sync = training.GradSync(model)
     torch.cuda.reset_peak_memory_stats(dev)
     g = torch.Generator().manual_seed(4321)
-    lens = torch.tensor([L - 37 * i for i in range(B)])
-    mask = (torch.arange(L)[None] < lens[:, None]).float().unsqueeze(1).to(dev)
-    mask_l = mask.clone()
-    mask_l[:, :, : L // 4] = 0
-    mask_l[:, :, L // 2:] = 0
-    x1 = torch.randn(B, 80, L, generator=g).to(dev) * mask_l
-    mu = torch.randn(B, 162, L, generator=g).to(dev) * mask
-    spk = torch.randn(B, 256, generator=g).to(dev)
+    lens = torch.tensor([L - 37 * i for i in range(B)]).to(dev)
+    x, logmel = torch.randn(B, L, 768, generator=g).to(dev), torch.randn(B, L, 80, generator=g).to(dev)
+    midi, lft = torch.randn(B, L, 1, generator=g).to(dev), torch.randn(B, L, 1, generator=g).to(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phases = {"forward_ms": 0.0, "backward_ms": 0.0, "optimizer_ms": 0.0}
     loss0 = loss = None
     for it in range(steps + 1):  # one warm-up
         e = [ev() for _ in range(4)]
-        est.zero_grad()
+        model.zero_grad()
         e[0].record()
-        loss, _ = training.cfm_loss(est, x1, mask, mu, spk, mask_l)
+        ret = model(x, lens, logmel, midi, lft)
+        loss = ret["cfm_loss"] + ret["prior_loss"]
         e[1].record()
         loss.backward()
         sync.finish()
@@ -91,10 +87,11 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
             for k, (a, b) in zip(phases, ((0, 1), (1, 2), (2, 3))):
                 phases[k] += e[a].elapsed_time(e[b]) / steps
     dt = (time.perf_counter() - t0) / steps
-    fl = 3.0 * B * (81.3e6 * L + 24576.0 * L * L)
-    return {"workload": f"estimator training step, B={B} x L={L} (ragged lengths), exact fp32, AdamW lr 8e-4 clip 1.0",
+    fl = 3.0 * B * (81.3e6 * L + 24576.0 * L * L + 11.32e6 * L)
+    return {"workload": f"whole-model training step (encoder + GST + estimator, cfm + prior loss), B={B} x L={L} "
+                        f"(ragged lengths), exact fp32, dropout 0.05, clip 1.0, AdamW lr 8e-4",
             "ms_per_step": dt * 1e3, "frames_per_s": B * L / dt, "tflops": fl / dt / 1e12,
-            "parameters": int(sum(v.numel() for v in est.params.values())), **phases,
+            "parameters": int(sum(v.numel() for v in model.params.values())), **phases,
             "loss_first": loss0, "loss_last": float(loss), "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2**30}
 
 

@@ -84,16 +84,20 @@ def conv1d_resnet(w, x):
 
 
 # --------------------------------------------------------------------------- a5 GST
-def reference_encoder(w, speech):
+def reference_encoder(w, speech, bn_training=False):
     """ReferenceEncoder.forward, serenade/modules/gst/style_encoder.py:171-191.
-    speech (B, T_ref, 80) -> (B, gru_units).  BatchNorm2d in eval mode (running stats)."""
+    speech (B, T_ref, 80) -> (B, gru_units).  BatchNorm2d in eval mode (running stats) unless bn_training
+    (model.train(): batch statistics; the running statistics are not updated here)."""
     h = speech.unsqueeze(1)
     i = 0
     while f"convs.{3 * i}.weight" in w:
         c, b = 3 * i, 3 * i + 1
         h = F.conv2d(h, w[f"convs.{c}.weight"], None, stride=2, padding=1)
-        h = F.batch_norm(h, w[f"convs.{b}.running_mean"], w[f"convs.{b}.running_var"],
-                         w[f"convs.{b}.weight"], w[f"convs.{b}.bias"], False, 0.0, 1e-5)
+        if bn_training:
+            h = F.batch_norm(h, None, None, w[f"convs.{b}.weight"], w[f"convs.{b}.bias"], True, 0.0, 1e-5)
+        else:
+            h = F.batch_norm(h, w[f"convs.{b}.running_mean"], w[f"convs.{b}.running_var"],
+                             w[f"convs.{b}.weight"], w[f"convs.{b}.bias"], False, 0.0, 1e-5)
         h = F.relu(h)
         i += 1
     h = h.transpose(1, 2)  # (B, T', C, F')
@@ -138,9 +142,9 @@ def style_token_layer(w, ref_embs, n_head=4):
     return ctx @ w["mha.linear_out.weight"].t() + w["mha.linear_out.bias"]
 
 
-def style_encoder(w, speech):
+def style_encoder(w, speech, bn_training=False):
     """StyleEncoder.forward, style_encoder.py:78-91."""
-    return style_token_layer(_sub(w, "stl."), reference_encoder(_sub(w, "ref_enc."), speech))
+    return style_token_layer(_sub(w, "stl."), reference_encoder(_sub(w, "ref_enc."), speech, bn_training))
 
 
 # --------------------------------------------------------------------------- a4 UNet
@@ -352,13 +356,14 @@ def cfm_compute_loss(w, x1, mask, mu, spk, mask_l, t, z, sigma_min=1e-4):
     return loss / denom, y
 
 
-def serenade_forward(w, x, lengths, logmel, midi, lft, uniform, seg_start, t, z, mask_size=(0.1, 0.5)):
+def serenade_forward(w, x, lengths, logmel, midi, lft, uniform, seg_start, t, z, mask_size=(0.1, 0.5),
+                     bn_training=False):
     """Serenade.forward, serenade/models/serenade.py:90-166.  `uniform` is the value random.uniform(*mask_size)
     returned, `seg_start` the value of random.randint, (t, z) the draws of CFM.compute_loss."""
     ret = {}
     enc = conv1d_resnet(_sub(w, "encoder."), x)
     ret["gauss_mel"] = enc
-    spk = style_encoder(_sub(w, "gst."), logmel)
+    spk = style_encoder(_sub(w, "gst."), logmel, bn_training)
     mask = make_non_pad_mask(lengths).unsqueeze(1)
     msize = int(uniform * enc.size(1))
     seg_end = seg_start + msize

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .ops import ConvOp
 
-__all__ = ["Estimator", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
+__all__ = ["Estimator", "TrainSerenade", "ParamStore", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
 
 
 def _require_cuda(t, what):
@@ -113,7 +113,7 @@ class _Conv(torch.autograd.Function):
             # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- contraction over time: rocBLAS.
             # Stride 1: one transposed-A GEMM per tap over the batch-flattened rows; both operands carry P zero rows
             # between batch items, so a tap's shift never pairs rows of different items.
-            if stride == 1:
+            if stride == 1 and T_out == T:
                 P = max(abs(o) for o in taps)
                 xp = F.pad(x, (0, 0, P, P)).reshape(-1, C) if P else x.reshape(-1, C)
                 dyp = F.pad(dy, (0, 0, P, P)).reshape(-1, N) if P else dy.reshape(-1, N)
@@ -134,13 +134,16 @@ class _Conv(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
-def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False):
-    """channels-last conv / linear over the HIP contraction kernel.  x (B, T, C) or (rows, C); w packed (N, k * C)."""
+def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None):
+    """channels-last conv / linear over the HIP contraction kernel.  x (B, T, C) or (rows, C); w packed (N, k * C).
+    T_out (stride 1 only): number of output rows when the input was padded by the caller (taps >= 0, "valid" conv)."""
     two_d = x.dim() == 2
     if two_d:
         x = x.unsqueeze(0)
     T = x.shape[1]
-    if stride == 1:
+    if T_out is not None:
+        assert stride == 1 and max(taps) + T_out <= T
+    elif stride == 1:
         T_out = T
     else:  # torch Conv1d with padding (k - 1) / 2: taps -p .. p
         p = -min(taps)
@@ -342,23 +345,19 @@ def sinusoidal_pos_emb(t, dim, scale=1000.0):
     return torch.cat((arg.sin(), arg.cos()), dim=-1)
 
 
-class Estimator:
-    """`Decoder` (matcha_components/decoder.py:196-467) for training: parameters under the reference's names and
-    shapes (`self.params`), each a view of the flat buffer `self.flat`; gradients are views of `self.flat_grad`.
+class ParamStore:
+    """Trainable tensors under their state_dict names, every one a view of ONE flat fp32 buffer (`flat`) with its
+    gradient a view of `flat_grad` (autograd accumulates in place): what the all-reduce and the optimizer work on.
+    Tensors in `skip` (BatchNorm running statistics) are not parameters and stay out."""
 
-    `forward(x, mask, mu, t, spks)` takes the reference's layouts -- x (B, out_ch, L), mask (B, 1, L), mu (B, cond, L),
-    t (B,), spks (B, S) -- and returns (B, out_ch, L) with an autograd graph whose backward runs on the HIP kernels."""
-
-    N_HEAD, GROUPS = 4, 8
-
-    def __init__(self, state_dict, device):
-        names = [k for k in state_dict if not k.endswith("num_batches_tracked")]
+    def __init__(self, state_dict, device, skip=()):
+        names = [k for k in state_dict if k not in skip]
         sizes = [state_dict[k].numel() for k in names]
-        # 4-float alignment of every view (16-B loads in the kernels)
         offs, o = [], 0
-        for n in sizes:
+        for n in sizes:  # 4-float alignment of every view (16-B loads in the kernels)
             offs.append(o)
             o += _rup(n, 4)
+        self.device = device
         self.flat = torch.zeros(o, device=device, dtype=torch.float32)
         self.flat_grad = torch.zeros(o, device=device, dtype=torch.float32)
         self.params, self.spans = {}, {}
@@ -369,7 +368,36 @@ class Estimator:
             v.grad = self.flat_grad[off:off + n].view(state_dict[k].shape)
             self.params[k] = v
             self.spans[k] = (off, n)
-        self.device = device
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+
+class Estimator:
+    """`Decoder` (matcha_components/decoder.py:196-467) for training: parameters under the reference's names and
+    shapes (`self.params`), each a view of the flat buffer `self.flat`; gradients are views of `self.flat_grad`.
+
+    `forward(x, mask, mu, t, spks)` takes the reference's layouts -- x (B, out_ch, L), mask (B, 1, L), mu (B, cond, L),
+    t (B,), spks (B, S) -- and returns (B, out_ch, L) with an autograd graph whose backward runs on the HIP kernels."""
+
+    N_HEAD, GROUPS = 4, 8
+
+    def __init__(self, state_dict, device, dropout=0.0, _store=None, _prefix=""):
+        """state_dict: the estimator's tensors under the reference's names.  dropout: probability of the two Dropout
+        layers of every transformer block (attention output, feed-forward; decoder.py:215 trains with 0.05) -- torch's
+        generator, so not reproducible against the reference's draws; parity tests use 0."""
+        if _store is None:
+            _store = ParamStore(state_dict, device)
+        self.store = _store
+        self.flat, self.flat_grad, self.device = _store.flat, _store.flat_grad, _store.device
+        n = len(_prefix)
+        self.params = {k[n:]: v for k, v in _store.params.items() if k.startswith(_prefix)}
+        self.spans = {k[n:]: v for k, v in _store.spans.items() if k.startswith(_prefix)}
+        self.dropout = float(dropout)
+        names = list(self.params)
         self.n_down = sum(1 for k in names if k.startswith("down_blocks.") and k.endswith(".0.mlp.1.weight"))
         self.n_mid = sum(1 for k in names if k.startswith("mid_blocks.") and k.endswith(".0.mlp.1.weight"))
         self.n_up = sum(1 for k in names if k.startswith("up_blocks.") and k.endswith(".0.mlp.1.weight"))
@@ -379,6 +407,9 @@ class Estimator:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def _drop(self, x):
+        return F.dropout(x, self.dropout, True) if self.dropout > 0.0 else x
 
     # ---- blocks ------------------------------------------------------------------------------------------------
     def _lin(self, x, name, bias=True, c_pad=None):
@@ -410,9 +441,9 @@ class Estimator:
         n = row_ln(x, P[p + "norm1.weight"], P[p + "norm1.bias"])
         wqkv = torch.cat([P[p + "attn1.to_q.weight"], P[p + "attn1.to_k.weight"], P[p + "attn1.to_v.weight"]], dim=0)
         o = attention_core(conv1d(n, wqkv, None), lens, self.N_HEAD)
-        x = conv1d(o, P[p + "attn1.to_out.0.weight"], P[p + "attn1.to_out.0.bias"]) + x
+        x = self._drop(conv1d(o, P[p + "attn1.to_out.0.weight"], P[p + "attn1.to_out.0.bias"])) + x
         n = row_ln(x, P[p + "norm3.weight"], P[p + "norm3.bias"])
-        a = geglu(conv1d(n, P[p + "ff.net.0.proj.weight"], P[p + "ff.net.0.proj.bias"]))
+        a = self._drop(geglu(conv1d(n, P[p + "ff.net.0.proj.weight"], P[p + "ff.net.0.proj.bias"])))
         return conv1d(a, P[p + "ff.net.2.weight"], P[p + "ff.net.2.bias"]) + x
 
     def forward(self, x, mask, mu, t, spks):
@@ -515,6 +546,145 @@ def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1
     loss = F.mse_loss(den, u, reduction="sum")
     denom = torch.sum(mask_l) if mask_l is not None else torch.sum(mask)
     return loss / (denom * u.shape[1]), y
+
+
+# =====================================================================================================================
+#  the whole model: Serenade.forward (serenade.py:90-166) for training
+# =====================================================================================================================
+def _reflect_pad_rows(x, p):
+    """nn.ReflectionPad1d(p) along time of a channels-last (B, T, C) tensor (a gather: autograd scatters back)"""
+    T = x.shape[1]
+    idx = torch.cat([torch.arange(p, 0, -1), torch.arange(T), torch.arange(T - 2, T - 2 - p, -1)]).to(x.device)
+    return x.index_select(1, idx)
+
+
+class TrainSerenade:
+    """`Serenade` (serenade/models/serenade.py:35-166) for training: all trainable tensors of the checkpoint in one
+    `ParamStore`; `forward` returns {"gauss_mel", "prior_loss", "cfm_loss"} with an autograd graph.
+
+      * estimator: `Estimator` above (HIP forward and backward);
+      * content encoder `Conv1dResnet` (serenade.py:282-296,310-376): weight-norm folded by torch ops, reflection
+        padding as a row gather, every conv through `conv1d` (HIP forward, dgrad; rocBLAS wgrad), LeakyReLU in torch;
+      * GST style encoder (modules/gst/style_encoder.py): six 3x3 stride-2 Conv2d + train-mode BatchNorm2d + ReLU, a
+        GRU over T_ref / 64 steps and the 50-token attention -- 0.8 GFLOP of the step's ~1.3 TFLOP -- run on
+        torch's GPU ops (MIOpen / rocBLAS) in both directions: the library path, not hand-written kernels.
+    BatchNorm running statistics are updated like nn.BatchNorm2d (momentum 0.1) in `self.buffers`."""
+
+    def __init__(self, state_dict, device, dropout=0.05, mask_size=(0.1, 0.5), output_dim=80):
+        skip = [k for k in state_dict if k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+        self.store = ParamStore(state_dict, device, skip=skip)
+        self.buffers = {k: state_dict[k].to(device).clone() for k in skip}
+        self.flat, self.flat_grad, self.device = self.store.flat, self.store.flat_grad, device
+        self.params, self.spans = self.store.params, self.store.spans
+        self.estimator = Estimator(None, device, dropout=dropout, _store=self.store, _prefix="cfm_decoder.estimator.")
+        self.mask_size, self.output_dim, self.training = tuple(mask_size), output_dim, True
+
+    def zero_grad(self):
+        self.store.zero_grad()
+
+    def state_dict(self):
+        sd = self.store.state_dict()
+        sd.update({k: v.clone() for k, v in self.buffers.items()})
+        return sd
+
+    # ---- content encoder -----------------------------------------------------------------------------------------
+    def _wn(self, name):
+        P = self.params
+        if name + ".weight" in P:
+            return P[name + ".weight"]
+        g, v = P[name + ".weight_g"], P[name + ".weight_v"]
+        return v * (g / v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape))
+
+    def encoder(self, x):
+        """(B, T, in_dim) -> (B, T, out_dim); like the reference, padded frames are not masked here"""
+        P, T = self.params, x.shape[1]
+        e = "encoder.model."
+        h = conv1d(_reflect_pad_rows(x.contiguous(), 3), pack_conv(self._wn(e + "1")), P[e + "1.bias"], range(7), T_out=T)
+        n = 0
+        while f"{e}{2 + n}.shortcut.bias" in P:
+            p, d = f"{e}{2 + n}", 2 ** n
+            sc = conv1d(h, pack_conv(self._wn(p + ".shortcut")), P[p + ".shortcut.bias"])
+            b = conv1d(_reflect_pad_rows(F.leaky_relu(h, 0.2), d), pack_conv(self._wn(p + ".block.2")),
+                       P[p + ".block.2.bias"], [0, d, 2 * d], T_out=T)
+            b = conv1d(F.leaky_relu(b, 0.2), pack_conv(self._wn(p + ".block.4")), P[p + ".block.4.bias"])
+            h = sc + b
+            n += 1
+        last = f"{e}{2 + n + 2}"
+        return conv1d(_reflect_pad_rows(F.leaky_relu(h, 0.2), 3), pack_conv(self._wn(last)), P[last + ".bias"],
+                      range(7), T_out=T)
+
+    # ---- GST (library path) ----------------------------------------------------------------------------------------
+    def gst(self, speech, n_head=4):
+        """StyleEncoder.forward (style_encoder.py:78-91,171-191,235-252) on torch GPU ops"""
+        P, Bf = self.params, self.buffers
+        r = "gst.ref_enc."
+        h = speech.unsqueeze(1)
+        i = 0
+        while f"{r}convs.{3 * i}.weight" in P:
+            c, b = f"{r}convs.{3 * i}", f"{r}convs.{3 * i + 1}"
+            h = F.conv2d(h, P[c + ".weight"], None, stride=2, padding=1)
+            h = F.batch_norm(h, Bf[b + ".running_mean"], Bf[b + ".running_var"], P[b + ".weight"], P[b + ".bias"],
+                             self.training, 0.1, 1e-5)
+            if self.training and b + ".num_batches_tracked" in Bf:
+                Bf[b + ".num_batches_tracked"] += 1
+            h = F.relu(h)
+            i += 1
+        h = h.transpose(1, 2)
+        bsz, tlen = h.shape[0], h.shape[1]
+        xs = h.contiguous().view(bsz, tlen, -1)
+        wih, whh = P[r + "gru.weight_ih_l0"], P[r + "gru.weight_hh_l0"]
+        bih, bhh = P[r + "gru.bias_ih_l0"], P[r + "gru.bias_hh_l0"]
+        hd = whh.shape[1]
+        gi_all = xs @ wih.t() + bih
+        hh = xs.new_zeros(bsz, hd)
+        for t in range(tlen):  # gate order r, z, n (torch.nn.GRU)
+            gi, gh = gi_all[:, t], hh @ whh.t() + bhh
+            rg = torch.sigmoid(gi[:, :hd] + gh[:, :hd])
+            zg = torch.sigmoid(gi[:, hd:2 * hd] + gh[:, hd:2 * hd])
+            ng = torch.tanh(gi[:, 2 * hd:] + rg * gh[:, 2 * hd:])
+            hh = (1.0 - zg) * ng + zg * hh
+        m = "gst.stl.mha."
+        toks = torch.tanh(P["gst.stl.gst_embs"])
+        q = hh @ P[m + "linear_q.weight"].t() + P[m + "linear_q.bias"]
+        k = toks @ P[m + "linear_k.weight"].t() + P[m + "linear_k.bias"]
+        v = toks @ P[m + "linear_v.weight"].t() + P[m + "linear_v.bias"]
+        nf = q.shape[-1]
+        dk = nf // n_head
+        scores = torch.einsum("bhd,thd->bht", q.view(bsz, n_head, dk), k.view(-1, n_head, dk)) / math.sqrt(dk)
+        ctx = torch.einsum("bht,thd->bhd", torch.softmax(scores, dim=-1), v.view(-1, n_head, dk)).reshape(bsz, nf)
+        return ctx @ P[m + "linear_out.weight"].t() + P[m + "linear_out.bias"]
+
+    # ---- Serenade.forward ----------------------------------------------------------------------------------------
+    def forward(self, x, lengths, logmel, midi, lft, draws=None):
+        """serenade.py:90-166.  `draws` (tests) = {"uniform", "seg_start", "t", "z"} replaces the random draws."""
+        import random
+        _require_cuda(x, "TrainSerenade.forward")
+        ret = {}
+        enc = self.encoder(x.to(torch.float32))
+        ret["gauss_mel"] = enc
+        spk = self.gst(logmel)
+        B, T = enc.shape[0], enc.shape[1]
+        mask = (torch.arange(T, device=x.device)[None] < torch.as_tensor(lengths, device=x.device)[:, None])
+        mask = mask.unsqueeze(1).to(torch.float32)
+        uni = random.uniform(*self.mask_size) if draws is None else float(draws["uniform"])
+        msize = int(uni * T)
+        s0 = random.randint(0, T - msize) if draws is None else int(draws["seg_start"])
+        mask_l = mask.clone()
+        mask_l[:, :, :s0] = 0
+        mask_l[:, :, s0 + msize:] = 0
+        mask_c = mask.clone()
+        mask_c[:, :, s0:s0 + msize] = 0
+        prior = torch.sum(0.5 * ((logmel.permute(0, 2, 1) - enc.permute(0, 2, 1)) ** 2 + math.log(2 * math.pi)) * mask)
+        ret["prior_loss"] = prior / (torch.sum(mask) * self.output_dim)
+        targets = logmel * mask_l.permute(0, 2, 1)
+        cond = logmel * mask_c.permute(0, 2, 1)
+        mu = torch.cat([enc, midi, lft, cond], dim=-1)
+        ret["cfm_loss"], _ = cfm_loss(self.estimator, targets.permute(0, 2, 1), mask, mu.permute(0, 2, 1), spk, mask_l,
+                                      draws=None if draws is None else {"t": draws["t"], "z": draws["z"]})
+        return ret
+
+    __call__ = forward
+
 
 
 # =====================================================================================================================

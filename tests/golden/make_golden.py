@@ -285,6 +285,88 @@ def train_grads_case():
     npz("train_grads_L45", **out)
 
 
+FULL_WHOLE = ["encoder.model.1.weight_g", "encoder.model.3.shortcut.weight_g", "encoder.model.6.bias",
+              "encoder.model.2.block.2.bias", "gst.ref_enc.convs.0.weight", "gst.ref_enc.convs.1.weight",
+              "gst.ref_enc.convs.16.bias", "gst.ref_enc.gru.bias_ih_l0", "gst.ref_enc.gru.bias_hh_l0",
+              "gst.stl.gst_embs", "gst.stl.mha.linear_out.bias", "gst.stl.mha.linear_k.bias",
+              "cfm_decoder.estimator.final_proj.bias", "cfm_decoder.estimator.mid_blocks.0.1.0.norm1.weight",
+              "cfm_decoder.estimator.down_blocks.0.0.speaker_projection.W_scale.bias"]
+FULL_ROWS = ["encoder.model.1.weight_v", "encoder.model.2.block.2.weight_v", "encoder.model.3.block.4.weight_v",
+             "encoder.model.6.weight_v", "gst.ref_enc.convs.15.weight", "gst.ref_enc.convs.6.weight",
+             "gst.ref_enc.gru.weight_ih_l0", "gst.ref_enc.gru.weight_hh_l0", "gst.stl.mha.linear_q.weight",
+             "gst.stl.mha.linear_v.weight", "cfm_decoder.estimator.down_blocks.0.0.block1.block.0.weight",
+             "cfm_decoder.estimator.up_blocks.0.2.conv.weight"]
+
+
+def train_full_case():
+    """f4, whole model: the reference's Serenade.forward (serenade.py:90-166) in train() mode -- BatchNorm on batch
+    statistics -- with every nn.Dropout set to p = 0, loss = cfm_loss + prior_loss (trainers/ssc.py:77-82), backward().
+    Stored: inputs, the draws (python random for the infill segment, torch.rand / randn_like for t, z), both losses,
+    whole / 4-row gradients of encoder, GST and estimator tensors, the global gradient norm over all parameters, and
+    one BatchNorm layer's running statistics after the step.
+
+        PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py train_full
+    """
+    import random
+    torch.set_grad_enabled(True)
+    model = Serenade(**SERENADE_PARAMS)
+    model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    rng = np.random.default_rng(781)
+    lens = [64, 49, 57]
+    B, T = len(lens), 64
+    x, logmel = rnd(rng, B, T, 768), rnd(rng, B, T, 80)
+    midi, lft = rnd(rng, B, T, 1), rnd(rng, B, T, 1)
+    draws = {}
+    o_uniform, o_randint, o_rand, o_randn_like = random.uniform, random.randint, torch.rand, torch.randn_like
+
+    def uniform(a, b):
+        draws["uniform"] = o_uniform(a, b)
+        return draws["uniform"]
+
+    def randint(a, b):
+        draws["seg_start"] = o_randint(a, b)
+        return draws["seg_start"]
+
+    def rand(*a, **k):
+        draws["t"] = o_rand(*a, **k)
+        return draws["t"]
+
+    def randn_like(t, **k):
+        draws["z"] = o_randn_like(t, **k)
+        return draws["z"]
+
+    random.seed(6)
+    torch.manual_seed(12)
+    random.uniform, random.randint, torch.rand, torch.randn_like = uniform, randint, rand, randn_like
+    try:
+        ret = model(x, torch.tensor(lens), logmel, midi, lft)
+    finally:
+        random.uniform, random.randint, torch.rand, torch.randn_like = o_uniform, o_randint, o_rand, o_randn_like
+    (ret["cfm_loss"] + ret["prior_loss"]).backward()
+    g = {k: p.grad for k, p in model.named_parameters()}
+    assert all(v is not None for v in g.values()), [k for k, v in g.items() if v is None]
+    total = torch.sqrt(sum((v.double() ** 2).sum() for v in g.values()))
+    sd = model.state_dict()
+    out = dict(lens=np.array(lens), x=x, logmel=logmel, midi=midi, lft=lft, uniform=np.float64(draws["uniform"]),
+               seg_start=np.int64(draws["seg_start"]), t=draws["t"], z=draws["z"], cfm_loss=ret["cfm_loss"],
+               prior_loss=ret["prior_loss"], gauss_mel=ret["gauss_mel"], grad_norm=total, n_params=np.int64(len(g)),
+               bn_mean=sd["gst.ref_enc.convs.16.running_mean"], bn_var=sd["gst.ref_enc.convs.16.running_var"])
+    for k in FULL_WHOLE:
+        out["g:" + k] = g[k]
+    for k in FULL_ROWS:
+        out["r:" + k] = g[k][:4]
+    npz("train_full_T64", **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "train_full":
+    train_full_case()
+    sys.exit(0)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "train":
     train_grads_case()
     sys.exit(0)

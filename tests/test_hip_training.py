@@ -187,3 +187,53 @@ def test_three_training_steps_match_torch_adamw(dev, weights):
     # Adam's first steps move every weight by ~lr regardless of the gradient's size, so compare the UPDATES
     worst = max((rel(est.params[k].detach().cpu() - weights[k], ref[k].detach() - weights[k]), k) for k in weights)
     assert worst[0] < 5e-2, worst
+
+
+def test_whole_model_gradients_match_the_reference(dev, golden):
+    """Serenade.forward in train() mode (BatchNorm on batch statistics, dropout off) + backward(), all 262 trainable
+    tensors: encoder (weight-norm, reflection padding), GST (library path), estimator, both losses"""
+    from tests.test_training_emulated import _full_case, check_whole_model
+    g = golden("train_full_T64")
+    c = _full_case(g)
+    model = training.TrainSerenade(serenade_weights(), dev, dropout=0.0)
+    d = dict(c["draws"], t=c["draws"]["t"].to(dev), z=c["draws"]["z"].to(dev))
+    ret = model(c["x"].to(dev), c["lengths"].to(dev), c["logmel"].to(dev), c["midi"].to(dev), c["lft"].to(dev), draws=d)
+    (ret["cfm_loss"] + ret["prior_loss"]).backward()
+    torch.cuda.synchronize()
+    check_whole_model(g, {k: v.detach().cpu() for k, v in ret.items()},
+                      {k: v.grad.detach().cpu() for k, v in model.params.items()})
+    assert rel(model.buffers["gst.ref_enc.convs.16.running_var"].cpu(), torch.from_numpy(g["bn_var"])) < 1e-4
+
+
+def test_training_loop_with_dropout_runs_and_learns(dev):
+    """the real configuration (dropout 0.05, random draws): five whole-model steps on one batch -- finite, the loss
+    falls, parameters of all three modules move, state_dict() round-trips into the inference model"""
+    from serenade_amd import models
+    from serenade_amd.utils.synth import SERENADE_PARAMS
+    torch.manual_seed(0)
+    import random
+    random.seed(0)
+    w = serenade_weights()
+    model = training.TrainSerenade(w, dev, dropout=0.05)
+    sync, opt = training.GradSync(model), training.AdamW(model, lr=8e-4, max_grad_norm=1.0)
+    B, T = 4, 96
+    g = torch.Generator().manual_seed(1)
+    x, logmel = torch.randn(B, T, 768, generator=g).to(dev), torch.randn(B, T, 80, generator=g).to(dev)
+    midi, lft = torch.randn(B, T, 1, generator=g).to(dev), torch.randn(B, T, 1, generator=g).to(dev)
+    lens = torch.tensor([96, 80, 70, 96]).to(dev)
+    losses = []
+    for _ in range(5):
+        model.zero_grad()
+        ret = model(x, lens, logmel, midi, lft)
+        loss = ret["cfm_loss"] + ret["prior_loss"]
+        loss.backward()
+        sync.finish()
+        n = opt.step()
+        assert math.isfinite(n) and math.isfinite(loss.item())
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    sd = model.state_dict()
+    for k in ("encoder.model.1.weight_v", "gst.stl.gst_embs", "cfm_decoder.estimator.final_proj.weight"):
+        assert not torch.equal(sd[k].cpu(), w[k])
+    inf = models.Serenade(**SERENADE_PARAMS)
+    inf.load_state_dict({k: v.cpu() for k, v in sd.items()})

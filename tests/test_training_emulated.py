@@ -117,3 +117,52 @@ def test_reference_gradient_fixture(golden):
         loss.backward()
     check_against_reference_gradients(g, loss.detach(), {k: v.grad for k, v in est.params.items()}, mu_r.grad,
                                       spk_r.grad)
+
+
+# ---- the whole model: Serenade.forward in train mode (BatchNorm on batch statistics, dropout off) ------------------
+def _full_case(g):
+    t = lambda k: torch.from_numpy(np.asarray(g[k]))
+    return dict(x=t("x"), lengths=torch.from_numpy(g["lens"]), logmel=t("logmel"), midi=t("midi"), lft=t("lft"),
+                draws={"uniform": float(g["uniform"]), "seg_start": int(g["seg_start"]), "t": t("t"), "z": t("z")})
+
+
+def check_whole_model(g, ret, grads, tol=3e-4):
+    for k in ("cfm_loss", "prior_loss"):
+        assert abs(float(ret[k].detach()) - float(g[k])) < 2e-5 * abs(float(g[k])), k
+    assert rel(ret["gauss_mel"].detach().cpu(), torch.from_numpy(g["gauss_mel"])) < 1e-4
+    assert len(grads) == int(g["n_params"])
+    for key in g:
+        if key[:2] not in ("g:", "r:"):
+            continue
+        ref = torch.from_numpy(g[key])
+        got = grads[key[2:]] if key[0] == "g" else grads[key[2:]][:4]
+        if ref.abs().max() < 1e-8:  # mathematically zero (the key bias of the token attention shifts every score alike)
+            assert got.abs().max() < 1e-8, key
+        else:
+            assert rel(got, ref) < tol, key
+    total = math.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    assert abs(total - float(g["grad_norm"])) < 2e-4 * float(g["grad_norm"])
+
+
+def test_whole_model_gradients_match_the_reference(golden):
+    """tests/golden/train_full_T64.npz = the reference's Serenade.forward in train() mode + backward(): pins the
+    oracle's autograd (bn_training) and the training model's host logic (encoder weight-norm / reflection padding, GST,
+    infill masks, both losses) through the emulator"""
+    g = golden("train_full_T64")
+    w = serenade_weights()
+    c = _full_case(g)
+    d = c["draws"]
+    wr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))
+              else v) for k, v in w.items()}
+    ret = O.serenade_forward(wr, c["x"], c["lengths"].tolist(), c["logmel"], c["midi"], c["lft"], d["uniform"],
+                             d["seg_start"], d["t"], d["z"], bn_training=True)
+    (ret["cfm_loss"] + ret["prior_loss"]).backward()
+    check_whole_model(g, ret, {k: v.grad for k, v in wr.items() if v.requires_grad})
+    with _emulator.installed():
+        model = training.TrainSerenade(w, torch.device("cpu"), dropout=0.0)
+        ret = model(c["x"], c["lengths"], c["logmel"], c["midi"], c["lft"], draws=d)
+        (ret["cfm_loss"] + ret["prior_loss"]).backward()
+    check_whole_model(g, ret, {k: v.grad for k, v in model.params.items()})
+    # BatchNorm running statistics moved like nn.BatchNorm2d's (momentum 0.1)
+    assert rel(model.buffers["gst.ref_enc.convs.16.running_mean"], torch.from_numpy(g["bn_mean"])) < 1e-4
+    assert rel(model.buffers["gst.ref_enc.convs.16.running_var"], torch.from_numpy(g["bn_var"])) < 1e-4
