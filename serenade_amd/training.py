@@ -72,7 +72,7 @@ class _Conv(torch.autograd.Function):
         y = torch.empty(B, T_out, N, device=x.device, dtype=torch.float32)
         part = None
         if want_gn:
-            part = torch.zeros(B, (T_out + 31) // 32, N // 32, 2, device=x.device, dtype=torch.float32)
+            part = torch.empty(B, (T_out + 31) // 32, N // 32, 2, device=x.device, dtype=torch.float32)
         _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part)
         ctx.save_for_backward(x, w)
         ctx.taps, ctx.stride, ctx.has_bias = tuple(taps), stride, bias is not None
@@ -255,12 +255,13 @@ class _AttnCore(torch.autograd.Function):
         Lp = _rup(L, 32)
         dev = qkv.device
         alpha = 1.0 / math.sqrt(hd)
-        P = torch.zeros(B, H, L, Lp, device=dev, dtype=torch.float32)
+        alloc = torch.empty if Lp == L else torch.zeros  # pad columns must read as zero
+        P = alloc(B, H, L, Lp, device=dev, dtype=torch.float32)
         ConvOp(in0=qkv, w=(qkv, inner), out=P, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=hd, N=L,
                in0_bs=L * three, in0_hs=hd, ld_in0=three, w_bs=L * three, w_hs=hd, ldw=three, out_bs=H * L * Lp,
                out_hs=L * Lp, ld_out=Lp, alpha=alpha, precision=_lib.PREC_FP32)()
         _call("srn_softmax_rows", P, lens, B * H, H, L, Lp)
-        vt = torch.zeros(B, inner, Lp, device=dev, dtype=torch.float32)  # V^T per head: (hd, Lp) k-major
+        vt = alloc(B, inner, Lp, device=dev, dtype=torch.float32)  # V^T per head: (hd, Lp) k-major
         vt[:, :, :L] = qkv[:, :, 2 * inner:].transpose(1, 2)
         o = torch.empty(B, L, inner, device=dev, dtype=torch.float32)
         ConvOp(in0=P, w=vt, out=o, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
@@ -282,13 +283,14 @@ class _AttnCore(torch.autograd.Function):
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
         # dP = dO V^T (rows of dO against rows of V: the Q K^T launch with other operands), then dS in place
-        dS = torch.zeros(B, H, L, Lp, device=dev, dtype=torch.float32)
+        alloc = torch.empty if Lp == L else torch.zeros
+        dS = alloc(B, H, L, Lp, device=dev, dtype=torch.float32)
         ConvOp(in0=do, w=(qkv, 2 * inner), out=dS, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=hd, N=L,
                in0_bs=L * inner, in0_hs=hd, ld_in0=inner, w_bs=L * three, w_hs=hd, ldw=three, out_bs=H * L * Lp,
                out_hs=L * Lp, ld_out=Lp, precision=_lib.PREC_FP32)()
         _call("srn_softmax_bwd", P, dS, B * H * L, L, Lp, 1.0 / math.sqrt(hd))
         # dQ = dS K: contraction over keys, K^T per head as the k-major operand
-        kt = torch.zeros(B, inner, Lp, device=dev, dtype=torch.float32)
+        kt = alloc(B, inner, Lp, device=dev, dtype=torch.float32)
         kt[:, :, :L] = qkv[:, :, inner:2 * inner].transpose(1, 2)
         ConvOp(in0=dS, w=kt, out=dqkv, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
                in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * three, out_hs=hd,
@@ -634,15 +636,10 @@ class TrainSerenade:
         xs = h.contiguous().view(bsz, tlen, -1)
         wih, whh = P[r + "gru.weight_ih_l0"], P[r + "gru.weight_hh_l0"]
         bih, bhh = P[r + "gru.bias_ih_l0"], P[r + "gru.bias_hh_l0"]
-        hd = whh.shape[1]
-        gi_all = xs @ wih.t() + bih
-        hh = xs.new_zeros(bsz, hd)
-        for t in range(tlen):  # gate order r, z, n (torch.nn.GRU)
-            gi, gh = gi_all[:, t], hh @ whh.t() + bhh
-            rg = torch.sigmoid(gi[:, :hd] + gh[:, :hd])
-            zg = torch.sigmoid(gi[:, hd:2 * hd] + gh[:, hd:2 * hd])
-            ng = torch.tanh(gi[:, 2 * hd:] + rg * gh[:, 2 * hd:])
-            hh = (1.0 - zg) * ng + zg * hh
+        # torch.nn.GRU's own fused op (MIOpen on the GPU): last hidden state, gate order r, z, n
+        _, hn = torch._VF.gru(xs, xs.new_zeros(1, bsz, whh.shape[1]), [wih, whh, bih, bhh], True, 1, 0.0, self.training,
+                              False, True)
+        hh = hn[0]
         m = "gst.stl.mha."
         toks = torch.tanh(P["gst.stl.gst_embs"])
         q = hh @ P[m + "linear_q.weight"].t() + P[m + "linear_q.bias"]
