@@ -60,6 +60,7 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
     opt = training.AdamW(model)
     sync = training.GradSync(model)
     torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)  # plans of the inference benchmark stay resident
     g = torch.Generator().manual_seed(4321)
     lens = torch.tensor([L - 37 * i for i in range(B)]).to(dev)
     x, logmel = torch.randn(B, L, 768, generator=g).to(dev), torch.randn(B, L, 80, generator=g).to(dev)
@@ -92,7 +93,7 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
                         f"(ragged lengths), exact fp32, dropout 0.05, clip 1.0, AdamW lr 8e-4",
             "ms_per_step": dt * 1e3, "frames_per_s": B * L / dt, "tflops": fl / dt / 1e12,
             "parameters": int(sum(v.numel() for v in model.params.values())), **phases,
-            "loss_first": loss0, "loss_last": float(loss), "peak_hbm_gib": torch.cuda.max_memory_allocated(dev) / 2**30}
+            "loss_first": loss0, "loss_last": float(loss), "peak_hbm_gib": (torch.cuda.max_memory_allocated(dev) - base) / 2**30}
 
 
 def build_id():
@@ -412,8 +413,6 @@ def main():
             out.setdefault("multi_gpu", {})[k] = head[k]
     for m in modes[1:]:
         out[MODE_KEY[m]] = results[m]
-    if rank == 0 and world == 1 and not args.no_sweep:
-        out["sweep"] = sweep()
     if rank == 0 and world == 1 and not args.no_train:
         serenade_amd.set_precision(modes[0])
         out["train_step"] = train_step_bench(dev, sd)
@@ -421,6 +420,8 @@ def main():
         big = train_step_bench(dev, sd, B=16)
         out["train_step"]["at_batch_16"] = {k: big[k] for k in ("ms_per_step", "frames_per_s", "tflops", "forward_ms",
                                                                 "backward_ms", "optimizer_ms", "peak_hbm_gib")}
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["sweep"] = sweep()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, gsd)
     if rank == 0:

@@ -1,27 +1,27 @@
-"""Training step of the flow-matching estimator on MI355X.
+"""Training step on MI355X.
 
-What the reference does per step (trainers/ssc.py:57-96, bin/ssc_train.py:331-359): `Serenade.forward` -> CFM loss
-(+ prior loss) -> `backward()` -> DDP gradient all-reduce over NCCL -> `clip_grad_norm_` -> AdamW.  Of that, this module
-builds the part with the FLOPs -- the estimator (matcha_components/decoder.py `Decoder`, 192 parameter tensors) under
-`CFM.compute_loss` (flow_matching.py:95-133):
+What the reference does per step (trainers/ssc.py:57-96, bin/ssc_train.py:331-359): `Serenade.forward` -> cfm_loss +
+prior_loss -> `backward()` -> DDP gradient all-reduce over NCCL -> `clip_grad_norm_(1.0)` -> AdamW(lr 8e-4).  Here:
 
-  * `Estimator`      the decoder with the reference's parameter names and shapes, all views into ONE flat fp32 buffer
-                     (and one flat gradient buffer), forward written over the same channels-last HIP kernels as
-                     inference, every op an autograd node whose backward is HIP again;
+  * `TrainSerenade`  the whole model (serenade.py:35-166) for training: every trainable tensor of the checkpoint under
+                     its reference name, all views of ONE flat fp32 buffer (and one flat gradient buffer);
+  * `Estimator`      the flow-matching decoder (matcha_components/decoder.py, 192 tensors, >99 % of the FLOPs): forward
+                     over the same channels-last HIP kernels as inference, every op an autograd node whose backward is
+                     HIP again; `cfm_loss` = flow_matching.py:95-133 around it;
   * `GradSync`       the DDP replacement: the flat gradient buffer is all-reduced over RCCL in buckets that are
                      launched from backward hooks as soon as their parameters are done (overlaps the rest of backward);
-  * `AdamW`          clip_grad_norm_ + torch.optim.AdamW as one fused kernel launch over the flat buffers (srn_adamw);
-  * `cfm_loss`       flow_matching.py:95-133 around the estimator.
+  * `AdamW`          clip_grad_norm_ + torch.optim.AdamW as one fused kernel launch over the flat buffers (srn_adamw).
 
 Division of labour.  GEMM-shaped gradients that contract over channels -- dgrad of every conv / projection (a conv of
 dY with the tap-reversed, transposed weights), dP = dO V^T and dQ = dS K of attention -- are `srn_conv_gemm` launches;
 row / column reductions and activations (GroupNorm+Mish, LayerNorm / SpeakerAdapter, softmax, GEGLU) are the kernels of
 csrc/train.hip.  Gradients that contract over TIME (wgrad = dY^T X, dV = P^T dO, dK = dS^T Q) are plain transposed-A
 GEMMs and go to rocBLAS through `torch.matmul` (the library-GEMM case).  torch autograd is the tape; mask multiplies,
-concatenations, the (B, 2048) time-embedding activations and scalar loss reductions are torch ops on the same device.
-The content encoder and the GST style encoder are NOT differentiated here: `mu` and `spks` are inputs, their gradients
-are returned for a caller that wants to continue (out of scope this round).  Dropout (p = 0.05 in the
-reference's transformer blocks while training) is not applied: parity is against the reference with dropout disabled.
+concatenations, LeakyReLU / dropout, weight-norm folding, the (B, 2048) time-embedding activations and the scalar loss
+reductions are torch ops on the same device.  The GST style encoder (0.8 GFLOP of a ~1.3 TFLOP step: 3x3 Conv2d +
+train-mode BatchNorm2d, a 16-step GRU, 50-token attention) runs on torch's GPU ops in both directions.  Dropout uses
+torch's generator (the reference's draws cannot be reproduced); parity tests run with dropout off against the
+reference's own gradients (tests/golden/train_grads_L45.npz, train_full_T64.npz).
 """
 import math
 
@@ -696,14 +696,16 @@ class GradSync:
     bucket's asynchronous all-reduce the moment the bucket's last gradient has landed -- the RCCL transfers of the
     late layers overlap the backward GEMMs of the early ones.  xGMI rings are per-link bound, so buckets are large
     (default 64 MiB: 3 collectives for the 44 M-parameter estimator).  `finish()` waits and divides by the world size.
-    World size 1 (or no process group) makes every call a no-op."""
+    World size 1 (or no process group) makes every call a no-op unless `always` (single-GPU rehearsal of the RCCL path)."""
 
-    def __init__(self, estimator, bucket_bytes=64 << 20, group=None):
+    def __init__(self, estimator, bucket_bytes=64 << 20, group=None, always=False):
         import torch.distributed as dist
         self.dist = dist
         self.est = estimator
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.always = bool(always) and dist.is_available() and dist.is_initialized()  # collectives even with one rank
+        self.launched = 0  # collectives issued so far (tests / logs)
         per = max(1, bucket_bytes // 4)
         total = estimator.flat.numel()
         self.buckets = []  # (start, end)
@@ -725,7 +727,7 @@ class GradSync:
         self._left = list(self.count)
         self._work = []
         self._hooks = []
-        if self.world > 1:
+        if self.world > 1 or self.always:
             for k, p in estimator.params.items():
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[k])))
 
@@ -738,12 +740,13 @@ class GradSync:
 
     def _launch(self, bi):
         s, e = self.buckets[bi]
+        self.launched += 1
         self._work.append(self.dist.all_reduce(self.est.flat_grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
     def finish(self):
         """call after backward(): launches whatever the hooks did not (unused parameters), waits, averages"""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         for bi, left in enumerate(self._left):
             if left > 0:
@@ -752,7 +755,8 @@ class GradSync:
             w.wait()
         self._work = []
         self._left = list(self.count)
-        self.est.flat_grad.div_(self.world)
+        if self.world > 1:
+            self.est.flat_grad.div_(self.world)
 
 
 class AdamW:

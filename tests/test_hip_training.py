@@ -237,3 +237,39 @@ def test_training_loop_with_dropout_runs_and_learns(dev):
         assert not torch.equal(sd[k].cpu(), w[k])
     inf = models.Serenade(**SERENADE_PARAMS)
     inf.load_state_dict({k: v.cpu() for k, v in sd.items()})
+
+
+_RCCL_ONE = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)   # before any other GPU call
+from serenade_amd import training
+g = torch.Generator().manual_seed(3)
+sd = {f"p{i}": torch.randn(s, generator=g) for i, s in enumerate([(700, 50), (3300,), (640, 90), (30,), (1280, 40)])}
+est = training.ParamStore(sd, dev)
+sync = training.GradSync(est, bucket_bytes=100000, always=True)
+coef = {k: torch.randn(v.shape, generator=g).to(dev) for k, v in sd.items()}
+for step in range(2):
+    est.zero_grad()
+    sum((est.params[k] * coef[k]).sum() for k in sd).backward()
+    sync.finish()
+    torch.cuda.synchronize()
+    assert all(torch.equal(est.params[k].grad, coef[k]) for k in sd)
+assert len(sync.buckets) >= 3 and sync.launched == 2 * len(sync.buckets), (sync.buckets, sync.launched)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", len(sync.buckets), dist.get_backend() if dist.is_initialized() else "nccl")
+"""
+
+
+def test_gradient_allreduce_over_rccl_group_of_one(dev):
+    """the DDP replacement's collective path on the GPU: a one-rank RCCL group, bucketed asynchronous all-reduce of
+    the flat gradient buffer launched from the backward hooks (N > 1 logic: gloo world-size-2 test on the CPU)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-2000:]
