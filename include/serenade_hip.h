@@ -302,6 +302,10 @@ int srn_geglu_bwd(const float* hg, const float* da, float* dhg, int64_t rows, in
  * clip_grad_norm_ coefficient of trainers/ssc.py:90-94), then p *= 1 - lr wd; m, v updated; p -= lr/bc1 m/(sqrt(v/bc2)+eps). */
 int srn_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, void* stream);
+/* The same update with the step-dependent scalars in device memory, dyn = {lr, 1 - beta1^step, 1 - beta2^step,
+ * grad_scale}: an identical launch every step, so a training step captured as a hipGraph can replay it. */
+int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                  float weight_decay, const float* dyn, void* stream);
 
 #ifdef __cplusplus
 }

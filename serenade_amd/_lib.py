@@ -85,6 +85,7 @@ _SIGS = {
     "srn_geglu_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "srn_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "srn_adamw": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "srn_adamw_dyn": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -348,6 +348,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// the same update with its step-dependent scalars read from device memory (dyn = {lr, bc1, bc2, grad_scale}): the
+// launch is then identical every step and can sit in a captured hipGraph
+__global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        float beta1, float beta2, float eps, float wd,
+                                                        const float* __restrict__ dyn) {
+  const float lr = dyn[0], bc1 = dyn[1], bc2 = dyn[2], gscale = dyn[3];
+  const float step = lr / bc1;
+  const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    pi -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi, m[i] = mi, v[i] = vi;
+  }
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 16384) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -436,6 +455,15 @@ extern "C" int srn_adamw(float* p, const float* g, float* m, float* v, int64_t n
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2, grad_scale);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                             float weight_decay, const float* dyn, void* stream) {
+  SRN_CHECK_ARG(p && g && m && v && dyn && n > 0, "adamw_dyn: bad args");
+  hipLaunchKernelGGL(adamw_dyn_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2,
+                     eps, weight_decay, dyn);
   SRN_CHECK_LAUNCH();
   return 0;
 }

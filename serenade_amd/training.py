@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .ops import ConvOp
 
-__all__ = ["Estimator", "TrainSerenade", "ParamStore", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
+__all__ = ["Estimator", "TrainSerenade", "ParamStore", "GraphedStep", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
 
 
 def _require_cuda(t, what):
@@ -106,7 +106,7 @@ class _Conv(torch.autograd.Function):
                     if not sel:
                         dx[:, ph::stride] = 0
                         continue
-                    wsel = wd[:, sel, :].reshape(C, len(sel) * N).contiguous()
+                    wsel = torch.stack([wd[:, j, :] for j in sel], dim=1).reshape(C, len(sel) * N)  # no host-side index tensor
                     _launch_conv(dy, wsel, None, dx, [(ph - taps[j]) // stride for j in sel], B, T_out, rows, N, C,
                                  out_t_stride=stride, out_t_off=ph, ld_out=C, out_bs=T * C)
         if ctx.needs_input_grad[1]:
@@ -556,7 +556,9 @@ def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1
 def _reflect_pad_rows(x, p):
     """nn.ReflectionPad1d(p) along time of a channels-last (B, T, C) tensor (a gather: autograd scatters back)"""
     T = x.shape[1]
-    idx = torch.cat([torch.arange(p, 0, -1), torch.arange(T), torch.arange(T - 2, T - 2 - p, -1)]).to(x.device)
+    d = x.device  # built on the device: a captured step may not copy from the host
+    idx = torch.cat([torch.arange(p, 0, -1, device=d), torch.arange(T, device=d),
+                     torch.arange(T - 2, T - 2 - p, -1, device=d)])
     return x.index_select(1, idx)
 
 
@@ -651,6 +653,12 @@ class TrainSerenade:
         ctx = torch.einsum("bht,thd->bhd", torch.softmax(scores, dim=-1), v.view(-1, n_head, dk)).reshape(bsz, nf)
         return ctx @ P[m + "linear_out.weight"].t() + P[m + "linear_out.bias"]
 
+    def draw_segment(self, T):
+        """(seg_start, seg_len) of the infill segment, drawn like serenade.py:117-119 (python `random`)"""
+        import random
+        msize = int(random.uniform(*self.mask_size) * T)
+        return random.randint(0, T - msize), msize
+
     # ---- Serenade.forward ----------------------------------------------------------------------------------------
     def forward(self, x, lengths, logmel, midi, lft, draws=None):
         """serenade.py:90-166.  `draws` (tests) = {"uniform", "seg_start", "t", "z"} replaces the random draws."""
@@ -663,21 +671,24 @@ class TrainSerenade:
         B, T = enc.shape[0], enc.shape[1]
         mask = (torch.arange(T, device=x.device)[None] < torch.as_tensor(lengths, device=x.device)[:, None])
         mask = mask.unsqueeze(1).to(torch.float32)
-        uni = random.uniform(*self.mask_size) if draws is None else float(draws["uniform"])
-        msize = int(uni * T)
-        s0 = random.randint(0, T - msize) if draws is None else int(draws["seg_start"])
-        mask_l = mask.clone()
-        mask_l[:, :, :s0] = 0
-        mask_l[:, :, s0 + msize:] = 0
-        mask_c = mask.clone()
-        mask_c[:, :, s0:s0 + msize] = 0
+        if draws is not None and "seg" in draws:  # device tensor [seg_start, seg_len] (a captured step replays it)
+            s0, msize = draws["seg"][0], draws["seg"][1]
+        else:
+            uni = random.uniform(*self.mask_size) if draws is None else float(draws["uniform"])
+            msize = int(uni * T)
+            s0 = random.randint(0, T - msize) if draws is None else int(draws["seg_start"])
+        idx = torch.arange(T, device=x.device)
+        inside = ((idx >= s0) & (idx < s0 + msize)).to(torch.float32).view(1, 1, T)
+        mask_l = mask * inside
+        mask_c = mask * (1.0 - inside)
         prior = torch.sum(0.5 * ((logmel.permute(0, 2, 1) - enc.permute(0, 2, 1)) ** 2 + math.log(2 * math.pi)) * mask)
         ret["prior_loss"] = prior / (torch.sum(mask) * self.output_dim)
         targets = logmel * mask_l.permute(0, 2, 1)
         cond = logmel * mask_c.permute(0, 2, 1)
         mu = torch.cat([enc, midi, lft, cond], dim=-1)
+        tz = None if draws is None or "t" not in draws else {"t": draws["t"], "z": draws["z"]}
         ret["cfm_loss"], _ = cfm_loss(self.estimator, targets.permute(0, 2, 1), mask, mu.permute(0, 2, 1), spk, mask_l,
-                                      draws=None if draws is None else {"t": draws["t"], "z": draws["z"]})
+                                      draws=tz)
         return ret
 
     __call__ = forward
@@ -698,7 +709,7 @@ class GradSync:
     (default 64 MiB: 3 collectives for the 44 M-parameter estimator).  `finish()` waits and divides by the world size.
     World size 1 (or no process group) makes every call a no-op unless `always` (single-GPU rehearsal of the RCCL path)."""
 
-    def __init__(self, estimator, bucket_bytes=64 << 20, group=None, always=False):
+    def __init__(self, estimator, bucket_bytes=64 << 20, group=None, always=False, overlap=True):
         import torch.distributed as dist
         self.dist = dist
         self.est = estimator
@@ -727,7 +738,7 @@ class GradSync:
         self._left = list(self.count)
         self._work = []
         self._hooks = []
-        if self.world > 1 or self.always:
+        if (self.world > 1 or self.always) and overlap:  # overlap=False: everything is launched by finish()
             for k, p in estimator.params.items():
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[k])))
 
@@ -769,6 +780,30 @@ class AdamW:
         self.m = torch.zeros_like(estimator.flat)
         self.v = torch.zeros_like(estimator.flat)
         self.steps = 0
+        self.dyn = torch.zeros(4, device=estimator.flat.device, dtype=torch.float32)  # lr, bc1, bc2, grad_scale
+        self.norm = torch.zeros((), device=estimator.flat.device, dtype=torch.float64)  # last gradient norm (device)
+
+    def prepare(self):
+        """host side of `step_captured`: advance the step count and upload {lr, 1 - beta1^t, 1 - beta2^t} (call before
+        every replay of a graph that contains `step_captured`)"""
+        self.steps += 1
+        h = torch.tensor([self.lr, 1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps],
+                         dtype=torch.float32)
+        self.dyn[:3].copy_(h, non_blocking=True)
+
+    def step_captured(self):
+        """the same update with no host synchronisation (gradient norm, clip factor and bias corrections stay on the
+        device): identical launches every step, so it can sit inside a captured hipGraph.  `prepare()` first."""
+        g = self.est.flat_grad
+        with torch.no_grad():
+            norm = torch.linalg.vector_norm(g, dtype=torch.float64)
+            self.norm.copy_(norm)
+            if self.max_norm and self.max_norm > 0:
+                self.dyn[3:4] = torch.clamp(self.max_norm / (norm + 1e-6), max=1.0).to(torch.float32)
+            else:
+                self.dyn[3:4] = 1.0
+            _call("srn_adamw_dyn", self.est.flat, g, self.m, self.v, g.numel(), self.betas[0], self.betas[1], self.eps,
+                  self.wd, self.dyn)
 
     def step(self):
         """returns the gradient norm before clipping (what clip_grad_norm_ returns)"""
@@ -783,3 +818,72 @@ class AdamW:
             _call("srn_adamw", self.est.flat, g, self.m, self.v, g.numel(), self.lr, self.betas[0], self.betas[1],
                   self.eps, self.wd, self.steps, scale)
         return norm
+
+
+class GraphedStep:
+    """One whole-model training step of a fixed (B, L) captured as a hipGraph and replayed.
+
+    At the reference's per-GPU batch (4) the eager step is bound by its ~2500 host-side launches; captured, the same
+    kernels run back to back.  Everything step-dependent lives in device memory: the inputs (static buffers the call
+    copies into), the infill segment (drawn on the host like the reference, uploaded as two integers), t / z / dropout
+    (the device generator, graph-safe), the clip factor and Adam's bias corrections (`AdamW.step_captured`).
+    With more than one rank the gradient all-reduce runs between two captured halves (backward | optimizer) on the whole
+    flat buffer.  Training batches of varying length need one GraphedStep per length bucket."""
+
+    def __init__(self, model, opt, B, L, in_dim=768, sync=None, warmup=2, tz=None):
+        """tz (tests): (t (B,1,1), z (B,out,L)) device tensors used instead of the generator's draws"""
+        dev = model.device
+        self.model, self.opt, self.sync, self.tz = model, opt, sync, tz
+        self.split = sync is not None and (sync.world > 1 or sync.always)
+        if self.split and sync._hooks:
+            raise ValueError("GraphedStep needs GradSync(..., overlap=False): collectives cannot sit inside the capture")
+        f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self.x, self.logmel, self.midi, self.lft = f(B, L, in_dim), f(B, L, model.output_dim), f(B, L, 1), f(B, L, 1)
+        self.lens = torch.full((B,), L, device=dev, dtype=torch.int64)
+        self.seg = torch.tensor([0, max(1, L // 4)], device=dev, dtype=torch.int64)
+        self.L = L
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # library handles, workspaces and autotuning settle outside the capture
+            for _ in range(warmup):
+                self._fwd_bwd()
+                opt.prepare()
+                opt.step_captured()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.g1, self.g2 = torch.cuda.CUDAGraph(), None
+        if self.split:
+            with torch.cuda.graph(self.g1):
+                self._fwd_bwd()
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+                opt.step_captured()
+        else:
+            with torch.cuda.graph(self.g1):
+                self._fwd_bwd()
+                opt.step_captured()
+
+    def _fwd_bwd(self):
+        self.model.zero_grad()
+        draws = {"seg": self.seg}
+        if self.tz is not None:
+            draws.update(t=self.tz[0], z=self.tz[1])
+        ret = self.model(self.x, self.lens, self.logmel, self.midi, self.lft, draws=draws)
+        self.cfm, self.prior = ret["cfm_loss"].detach(), ret["prior_loss"].detach()
+        (ret["cfm_loss"] + ret["prior_loss"]).backward()
+
+    def __call__(self, x, lengths, logmel, midi, lft, segment=None):
+        """returns (cfm_loss, prior_loss, grad_norm) as device tensors of the step just replayed"""
+        for dst, src in ((self.x, x), (self.logmel, logmel), (self.midi, midi), (self.lft, lft), (self.lens, lengths)):
+            dst.copy_(src, non_blocking=True)
+        s0, n = self.model.draw_segment(self.L) if segment is None else segment
+        self.seg.copy_(torch.tensor([s0, n], dtype=torch.int64), non_blocking=True)
+        self.opt.prepare()
+        self.g1.replay()
+        if self.split:
+            for a, b in self.sync.buckets:
+                self.sync.dist.all_reduce(self.model.flat_grad[a:b], group=self.sync.group)
+            if self.sync.world > 1:
+                self.model.flat_grad.div_(self.sync.world)
+            self.g2.replay()
+        return self.cfm, self.prior, self.opt.norm

@@ -374,6 +374,15 @@ def emul_call(name, a):
         with torch.enable_grad():
             (hv[:, :inner] * F.gelu(hv[:, inner:])).backward(_v(da, rows * inner).reshape(rows, inner))
         _v(dhg, rows * 2 * inner).reshape(rows, 2 * inner)[:] = hv.grad
+    elif name == "srn_adamw_dyn":
+        pp, g, m, v, n, b1, b2, eps, wd, dyn = a
+        lr, bc1, bc2, gscale = (float(x) for x in _v(dyn, 4))
+        pv, gv, mv, vv = (_v(t, n) for t in (pp, g, m, v))
+        gi = gv * gscale
+        pv.mul_(1 - lr * wd)
+        mv.mul_(b1).add_(gi, alpha=1 - b1)
+        vv.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        pv.addcdiv_(mv / bc1, (vv / bc2).sqrt() + eps, value=-lr)
     elif name == "srn_adamw":
         pp, g, m, v, n, lr, b1, b2, eps, wd, step, gscale = a
         pv, gv, mv, vv = (_v(t, n) for t in (pp, g, m, v))
