@@ -306,6 +306,10 @@ int srn_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
  * grad_scale}: an identical launch every step, so a training step captured as a hipGraph can replay it. */
 int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
                   float weight_decay, const float* dyn, void* stream);
+/* clip_grad_norm_'s total norm: partial[i], i < srn_sumsq_blocks(n) (<= 1024), = fp64 sums of squares of slices of g;
+ * the host adds them and takes the root. */
+int srn_sumsq(const float* g, int64_t n, double* partial, void* stream);
+int srn_sumsq_blocks(int64_t n);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,8 @@ _SIGS = {
     "srn_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "srn_adamw": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "srn_adamw_dyn": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
+    "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "srn_sumsq_blocks": (c_int, [c_int64]),
 }
 
 EXPORTS = tuple(_SIGS)

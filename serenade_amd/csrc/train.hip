@@ -367,6 +367,23 @@ __global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, c
   }
 }
 
+// sum of squares in fp64: partial[block] for <= 1024 blocks (the host adds them): clip_grad_norm_'s total norm
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4*>(g + i * 4);
+    acc += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)g[i] * g[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 16384) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -464,6 +481,15 @@ extern "C" int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64
   SRN_CHECK_ARG(p && g && m && v && dyn && n > 0, "adamw_dyn: bad args");
   hipLaunchKernelGGL(adamw_dyn_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2,
                      eps, weight_decay, dyn);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_sumsq_blocks(int64_t n) { return (int)grid_for((n + 7) / 8, 1024); }
+
+extern "C" int srn_sumsq(const float* g, int64_t n, double* partial, void* stream) {
+  SRN_CHECK_ARG(g && partial && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "sumsq: bad args");
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)srn_sumsq_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, partial);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -130,7 +130,8 @@ class _Conv(torch.autograd.Function):
                     mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
             dw = torch.stack(mats, dim=1).reshape(N, nt * C) if nt > 1 else mats[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 1))
+            # column sums as a GEMV (rocBLAS), not a torch reduction: see AdamW._grad_norm
+            db = torch.mv(dy.reshape(-1, N).t(), torch.ones(B * T_out, device=dy.device, dtype=torch.float32))
         return dx, dw, db, None, None, None, None
 
 
@@ -152,6 +153,21 @@ def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None):
     if two_d:
         return out.squeeze(0)
     return out
+
+
+class _AddRowBias(torch.autograd.Function):
+    """h (B, T, C) + b (B, C) broadcast over T.  Its backward's column sum is a batched GEMV (rocBLAS) instead of the
+    reduction autograd would insert for the broadcast: see AdamW._grad_norm."""
+
+    @staticmethod
+    def forward(ctx, h, b):
+        return h + b.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, C = dy.shape
+        ones = torch.ones(B, 1, T, device=dy.device, dtype=dy.dtype)
+        return dy, torch.bmm(ones, dy).squeeze(1)
 
 
 def pack_conv(w, c_pad=None):
@@ -377,6 +393,19 @@ class ParamStore:
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self.params.items()}
 
+    def backward_into_flat(self, loss):
+        """`flat_grad` <- d loss / d parameters, OVERWRITING it (no zero_grad needed): torch.autograd.grad + one
+        multi-tensor copy, every op on the current stream.  Used by captured steps: the per-leaf AccumulateGrad nodes of
+        `loss.backward()` run on the stream the leaf was created on, and the 262 in-place adds they issue from there
+        raced with the capture stream's reuse of the gradient temporaries."""
+        ps = list(self.params.values())
+        grads = torch.autograd.grad(loss, ps, allow_unused=True)
+        with torch.no_grad():
+            torch._foreach_copy_([p.grad for p, g in zip(ps, grads) if g is not None], [g for g in grads if g is not None])
+            for p, g in zip(ps, grads):
+                if g is None:
+                    p.grad.zero_()
+
 
 class Estimator:
     """`Decoder` (matcha_components/decoder.py:196-467) for training: parameters under the reference's names and
@@ -429,7 +458,7 @@ class Estimator:
     def _resnet(self, p, x, maskf, lens, temb, spk, c_pad=None):
         """ResnetBlock1D (decoder.py:80-101) + SpeakerAdapter (decoder.py:23-45)"""
         h = self._block1d(p + "block1.", x, maskf, lens, c_pad)
-        h = h + self._lin(F.mish(temb), p + "mlp.1").unsqueeze(1)
+        h = _AddRowBias.apply(h, self._lin(F.mish(temb), p + "mlp.1"))
         h = self._block1d(p + "block2.", h, maskf, lens)
         out = h + conv1d(x * maskf, pack_conv(self.params[p + "res_conv.weight"], c_pad), self.params[p + "res_conv.bias"])
         scale = self._lin(spk, p + "speaker_projection.W_scale")
@@ -530,6 +559,13 @@ def _convtranspose_phases(w, stride, padding):
     return out
 
 
+def _total(x):
+    """sum of all elements as a dot product (rocBLAS), not a torch reduction kernel: those return stale / zero results
+    when a captured hipGraph replays them on this stack (see AdamW._grad_norm); same value, same gradient"""
+    f = x.reshape(-1)
+    return torch.dot(f, torch.ones_like(f))
+
+
 def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1e-4):
     """CFM.compute_loss (flow_matching.py:95-133) with autograd through `estimator`.  `draws` = {"t": (B,1,1),
     "z": like x1} fixes the random draws (parity tests); otherwise torch.rand / randn_like as in the reference."""
@@ -545,8 +581,9 @@ def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1
     if mask_l is not None:
         den = den * mask_l
         u = u * mask_l
-    loss = F.mse_loss(den, u, reduction="sum")
-    denom = torch.sum(mask_l) if mask_l is not None else torch.sum(mask)
+    d = (den - u).reshape(-1)
+    loss = torch.dot(d, d)  # F.mse_loss(den, u, reduction="sum")
+    denom = _total(mask_l if mask_l is not None else mask.to(d.dtype))
     return loss / (denom * u.shape[1]), y
 
 
@@ -681,8 +718,12 @@ class TrainSerenade:
         inside = ((idx >= s0) & (idx < s0 + msize)).to(torch.float32).view(1, 1, T)
         mask_l = mask * inside
         mask_c = mask * (1.0 - inside)
-        prior = torch.sum(0.5 * ((logmel.permute(0, 2, 1) - enc.permute(0, 2, 1)) ** 2 + math.log(2 * math.pi)) * mask)
-        ret["prior_loss"] = prior / (torch.sum(mask) * self.output_dim)
+        # sum(0.5 * ((logmel - enc)^2 + log 2 pi) * mask) over (B, out, T), written with dot products (see _total)
+        diff = (logmel - enc).reshape(-1)
+        n_valid = _total(mask)
+        prior = 0.5 * torch.dot(diff * mask.permute(0, 2, 1).expand(B, T, self.output_dim).reshape(-1), diff) \
+            + 0.5 * math.log(2 * math.pi) * self.output_dim * n_valid
+        ret["prior_loss"] = prior / (n_valid * self.output_dim)
         targets = logmel * mask_l.permute(0, 2, 1)
         cond = logmel * mask_c.permute(0, 2, 1)
         mu = torch.cat([enc, midi, lft, cond], dim=-1)
@@ -781,7 +822,15 @@ class AdamW:
         self.v = torch.zeros_like(estimator.flat)
         self.steps = 0
         self.dyn = torch.zeros(4, device=estimator.flat.device, dtype=torch.float32)  # lr, bc1, bc2, grad_scale
+        self._ss = torch.zeros(1024, device=estimator.flat.device, dtype=torch.float64)  # srn_sumsq partial sums
         self.norm = torch.zeros((), device=estimator.flat.device, dtype=torch.float64)  # last gradient norm (device)
+
+    def _grad_norm(self):
+        """fp64 total gradient norm as a 0-dim device tensor (own kernel + a 1024-element sum: torch's multi-block
+        reductions gave wrong results when replayed inside a hipGraph on this stack)"""
+        g = self.est.flat_grad
+        _call("srn_sumsq", g, g.numel(), self._ss)
+        return torch.sqrt(self._ss.sum())
 
     def prepare(self):
         """host side of `step_captured`: advance the step count and upload {lr, 1 - beta1^t, 1 - beta2^t} (call before
@@ -789,14 +838,14 @@ class AdamW:
         self.steps += 1
         h = torch.tensor([self.lr, 1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps],
                          dtype=torch.float32)
-        self.dyn[:3].copy_(h, non_blocking=True)
+        self.dyn[:3].copy_(h)
 
     def step_captured(self):
         """the same update with no host synchronisation (gradient norm, clip factor and bias corrections stay on the
         device): identical launches every step, so it can sit inside a captured hipGraph.  `prepare()` first."""
         g = self.est.flat_grad
         with torch.no_grad():
-            norm = torch.linalg.vector_norm(g, dtype=torch.float64)
+            norm = self._grad_norm()
             self.norm.copy_(norm)
             if self.max_norm and self.max_norm > 0:
                 self.dyn[3:4] = torch.clamp(self.max_norm / (norm + 1e-6), max=1.0).to(torch.float32)
@@ -809,7 +858,7 @@ class AdamW:
         """returns the gradient norm before clipping (what clip_grad_norm_ returns)"""
         _require_cuda(self.est.flat, "AdamW.step")
         g = self.est.flat_grad
-        norm = float(torch.linalg.vector_norm(g, dtype=torch.float64))
+        norm = float(self._grad_norm())
         scale = 1.0
         if self.max_norm and self.max_norm > 0:
             scale = min(1.0, self.max_norm / (norm + 1e-6))
@@ -842,6 +891,9 @@ class GraphedStep:
         self.lens = torch.full((B,), L, device=dev, dtype=torch.int64)
         self.seg = torch.tensor([0, max(1, L // 4)], device=dev, dtype=torch.int64)
         self.L = L
+        # warm-up runs real steps (on the zero-filled static inputs): put weights, optimizer state and BatchNorm
+        # statistics back afterwards, so constructing a GraphedStep leaves the training state untouched
+        keep = (model.flat.clone(), opt.m.clone(), opt.v.clone(), opt.steps, {k: v.clone() for k, v in model.buffers.items()})
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # library handles, workspaces and autotuning settle outside the capture
@@ -862,22 +914,25 @@ class GraphedStep:
             with torch.cuda.graph(self.g1):
                 self._fwd_bwd()
                 opt.step_captured()
+        model.flat.copy_(keep[0]), opt.m.copy_(keep[1]), opt.v.copy_(keep[2])
+        opt.steps = keep[3]
+        for k, v in keep[4].items():
+            model.buffers[k].copy_(v)
 
     def _fwd_bwd(self):
-        self.model.zero_grad()
         draws = {"seg": self.seg}
         if self.tz is not None:
             draws.update(t=self.tz[0], z=self.tz[1])
         ret = self.model(self.x, self.lens, self.logmel, self.midi, self.lft, draws=draws)
         self.cfm, self.prior = ret["cfm_loss"].detach(), ret["prior_loss"].detach()
-        (ret["cfm_loss"] + ret["prior_loss"]).backward()
+        self.model.store.backward_into_flat(ret["cfm_loss"] + ret["prior_loss"])
 
     def __call__(self, x, lengths, logmel, midi, lft, segment=None):
         """returns (cfm_loss, prior_loss, grad_norm) as device tensors of the step just replayed"""
         for dst, src in ((self.x, x), (self.logmel, logmel), (self.midi, midi), (self.lft, lft), (self.lens, lengths)):
             dst.copy_(src, non_blocking=True)
         s0, n = self.model.draw_segment(self.L) if segment is None else segment
-        self.seg.copy_(torch.tensor([s0, n], dtype=torch.int64), non_blocking=True)
+        self.seg.copy_(torch.tensor([s0, n], dtype=torch.int64))
         self.opt.prepare()
         self.g1.replay()
         if self.split:

@@ -374,6 +374,11 @@ def emul_call(name, a):
         with torch.enable_grad():
             (hv[:, :inner] * F.gelu(hv[:, inner:])).backward(_v(da, rows * inner).reshape(rows, inner))
         _v(dhg, rows * 2 * inner).reshape(rows, 2 * inner)[:] = hv.grad
+    elif name == "srn_sumsq":
+        g, n, part = a
+        pv = _v(part)
+        pv.zero_()
+        pv[0] = (_v(g, n).double() ** 2).sum()
     elif name == "srn_adamw_dyn":
         pp, g, m, v, n, b1, b2, eps, wd, dyn = a
         lr, bc1, bc2, gscale = (float(x) for x in _v(dyn, 4))

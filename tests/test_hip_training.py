@@ -277,39 +277,44 @@ def test_gradient_allreduce_over_rccl_group_of_one(dev):
 
 def test_captured_step_equals_eager_step(dev):
     """GraphedStep: the whole-model step captured as a hipGraph (device-side infill segment, clip factor and Adam bias
-    corrections) replays to the same losses, gradient norm and weights as the eager step on the same draws"""
+    corrections).  (a) With the weights frozen (lr = 0) every replay reproduces the eager step's losses and ALL
+    gradients on three different batches -- torch's own multi-block reductions returned stale values from the second
+    replay on, which is why the step routes them through rocBLAS / srn_sumsq; (b) with the optimizer on, losses and
+    gradient norms track the eager run."""
     w = serenade_weights()
-    B, L = 2, 64
+    B, L = 4, 512  # large enough for multi-block reductions
     g = torch.Generator().manual_seed(8)
-    batches = [[torch.randn(B, L, 768, generator=g).to(dev), torch.tensor([64, 50]).to(dev),
+    batches = [[torch.randn(B, L, 768, generator=g).to(dev), torch.tensor([512, 400, 333, 512]).to(dev),
                 torch.randn(B, L, 80, generator=g).to(dev), torch.randn(B, L, 1, generator=g).to(dev),
                 torch.randn(B, L, 1, generator=g).to(dev)] for _ in range(3)]
     t, z = torch.rand(B, 1, 1, generator=g).to(dev), torch.randn(B, 80, L, generator=g).to(dev)
-    segs = [(10, 20), (0, 31), (40, 7)]
-    eager = training.TrainSerenade(w, dev, dropout=0.0)
-    opt_e = training.AdamW(eager)
-    ref = []
-    for (x, lens, mel, midi, lft), (s0, n) in zip(batches, segs):
-        eager.zero_grad()
-        ret = eager(x, lens, mel, midi, lft, draws={"seg": torch.tensor([s0, n]).to(dev), "t": t, "z": z})
-        (ret["cfm_loss"] + ret["prior_loss"]).backward()
-        norm = opt_e.step()
-        ref.append((ret["cfm_loss"].item(), ret["prior_loss"].item(), norm))
-    cap = training.TrainSerenade(w, dev, dropout=0.0)
-    opt_c = training.AdamW(cap)
-    step = training.GraphedStep(cap, opt_c, B, L, tz=(t, z), warmup=1)
-    # the warm-up / capture ran optimizer steps on zero inputs: restart from the checkpoint
-    cap.flat.copy_(eager_start := training.TrainSerenade(w, dev, dropout=0.0).flat)
-    opt_c.m.zero_(), opt_c.v.zero_()
-    opt_c.steps = 0
-    for k in cap.buffers:
-        cap.buffers[k].copy_(w[k].to(dev))
-    for (x, lens, mel, midi, lft), seg, r in zip(batches, segs, ref):
-        cfm, prior, norm = step(x, lens, mel, midi, lft, segment=seg)
-        torch.cuda.synchronize()
-        assert abs(cfm.item() - r[0]) < 1e-5 * abs(r[0]) and abs(prior.item() - r[1]) < 1e-5 * abs(r[1])
-        assert abs(float(norm) - r[2]) < 1e-4 * r[2]
-    # Adam's first steps move every weight by ~lr whatever its gradient's size: rounding noise in near-zero gradients
-    # shows up at percent level in a few elements; the bulk agrees to 1e-3
-    da, db = cap.flat.cpu() - eager_start.cpu(), eager.flat.cpu() - eager_start.cpu()
-    assert rel(da, db) < 8e-2 and ((da - db).abs().mean() / db.abs().mean()).item() < 1e-3
+    segs = [(100, 200), (0, 255), (300, 60)]
+    for lr in (0.0, 8e-4):
+        eager = training.TrainSerenade(w, dev, dropout=0.0)
+        opt_e = training.AdamW(eager, lr=lr, weight_decay=0.0 if lr == 0.0 else 0.01)
+        cap = training.TrainSerenade(w, dev, dropout=0.0)
+        opt_c = training.AdamW(cap, lr=lr, weight_decay=0.0 if lr == 0.0 else 0.01)
+        start = cap.flat.clone()
+        step = training.GraphedStep(cap, opt_c, B, L, tz=(t, z), warmup=1)
+        # building the captured step (warm-up steps on zero inputs) leaves weights, optimizer state and BatchNorm
+        # statistics alone
+        assert torch.equal(cap.flat, start) and opt_c.steps == 0 and not opt_c.m.any()
+        assert all(torch.equal(cap.buffers[k].cpu(), w[k]) for k in cap.buffers)
+        for i, ((x, lens, mel, midi, lft), seg) in enumerate(zip(batches, segs)):
+            eager.zero_grad()
+            ret = eager(x, lens, mel, midi, lft, draws={"seg": torch.tensor(seg).to(dev), "t": t, "z": z})
+            (ret["cfm_loss"] + ret["prior_loss"]).backward()
+            n_ref = opt_e.step()
+            cfm, prior, norm = step(x, lens, mel, midi, lft, segment=seg)
+            torch.cuda.synchronize()
+            tol = 1e-5 if (lr == 0.0 or i == 0) else 2e-4
+            assert abs(cfm.item() - ret["cfm_loss"].item()) < tol * abs(cfm.item()), (lr, i)
+            assert abs(prior.item() - ret["prior_loss"].item()) < tol * abs(prior.item()), (lr, i)
+            assert abs(float(norm) - n_ref) < 10 * tol * n_ref, (lr, i)
+            if lr == 0.0:
+                for k in cap.params:
+                    ref = eager.params[k].grad
+                    if ref.abs().max() > 1e-7:  # not the mathematically-zero key bias of the token attention
+                        assert rel(cap.params[k].grad.cpu(), ref.cpu()) < 1e-4, (i, k)
+        if lr == 0.0:
+            assert torch.equal(cap.flat, start)
