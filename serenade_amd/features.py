@@ -81,19 +81,25 @@ class _Stft:
         self.B, self.n, self.nb = B, n, 1 + n_fft // 2
         self.frames = 1 + n // hop
         pad = n_fft // 2
-        rows = -(-(n + 2 * pad) // c) + n_fft // c  # the last frame's taps stay inside the buffer
+        rows = -(-(n + 2 * pad) // c) + n_fft // c + 2  # the last frame's taps stay inside the buffer
         self.ld_sig = rows * c
         self.ld = _rup(2 * self.nb, 4)
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.audio, self.sig, self.spec = f(B, n), f(B, self.ld_sig), f(B, self.frames, self.ld)
         self.basis = torch.from_numpy(_dft_basis(n_fft, win_length, self.ld)).to(dev)
         self.ops = [ops.CallOp("srn_reflect_pad", (self.audio, self.sig, B, n, pad, self.ld_sig))]
-        taps_all = n_fft // c
+        # A frame is a contraction over n_fft samples = taps of `cw` samples each.  The signal is viewed as rows that START
+        # every c samples (row stride c, so any frame start is a row) but are cw = 32 samples WIDE (overlapping rows are
+        # fine for a read-only operand): 32-channel taps take the fast contraction kernel, 16-wide ones the generic one
+        # (loudness, n_fft 2048: 5.6 -> 0.9 ms per 8 x 1024 frames).
+        cw = 32 if (c == 16 and n_fft % 32 == 0) else c
+        step = cw // c
+        taps_all = n_fft // cw
         for g0 in range(0, taps_all, _lib.SRN_MAX_TAPS):
-            taps = list(range(g0, min(g0 + _lib.SRN_MAX_TAPS, taps_all)))
+            taps = [step * j for j in range(g0, min(g0 + _lib.SRN_MAX_TAPS, taps_all))]
             more = dict(res=self.spec, res_mode=ops.RES_ADD, res_bs=self.frames * self.ld, ld_res=self.ld) if g0 else {}
-            self.ops.append(ops.ConvOp(in0=self.sig, w=(self.basis, g0 * c), out=self.spec, n_batch=B, T_in=rows,
-                                       T_out=self.frames, C_in=c, N=self.ld, in0_bs=self.ld_sig, ld_in0=c, ldw=n_fft,
+            self.ops.append(ops.ConvOp(in0=self.sig, w=(self.basis, g0 * cw), out=self.spec, n_batch=B, T_in=rows - step,
+                                       T_out=self.frames, C_in=cw, N=self.ld, in0_bs=self.ld_sig, ld_in0=c, ldw=n_fft,
                                        out_bs=self.frames * self.ld, ld_out=self.ld, taps=taps, in_stride=hop // c,
                                        precision=_lib.PREC_FP32, **more))
 
