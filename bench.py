@@ -213,6 +213,35 @@ def cpu_baseline(sd, gsd):
             "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "one_thread": legs["one_thread"]}
 
 
+def cpu_train_baseline(sd, B=1, L=256):
+    """the training step's CPU side-by-side: Serenade.forward in train mode + backward by torch autograd through the
+    oracle on the usable host cores (no optimizer), one warm-up on a short clip, median of 3"""
+    from oracle import serenade_oracle as O
+    _, phys, usable = host_cpu()
+    threads = max(1, min(phys, usable))
+    saved = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        def run(T):
+            g = torch.Generator().manual_seed(5)
+            w = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))
+                     else v) for k, v in sd.items()}
+            x, mel = torch.randn(B, T, 768, generator=g), torch.randn(B, T, 80, generator=g)
+            midi, lft = torch.randn(B, T, 1, generator=g), torch.randn(B, T, 1, generator=g)
+            t, z = torch.rand(B, 1, 1, generator=g), torch.randn(B, 80, T, generator=g)
+            t0 = time.perf_counter()
+            ret = O.serenade_forward(w, x, [T] * B, mel, midi, lft, 0.3, T // 4, t, z, bn_training=True)
+            (ret["cfm_loss"] + ret["prior_loss"]).backward()
+            return time.perf_counter() - t0
+        run(64)
+        ts = [run(L) for _ in range(3)]
+    finally:
+        torch.set_num_threads(saved)
+    med = statistics.median(ts)
+    return {"value": B * L / med, "unit": "frames/s", "cores": threads, "kind": "port", "median_s": med,
+            "sample": f"B={B} x L={L} forward + backward through the oracle (torch autograd, fp32), median of 3"}
+
+
 # ---------------------------------------------------------------------------------------------------- traffic record
 def recorded_traffic(precision):
     """HBM-side bytes per contraction launch from the newest committed PMC record (tools/profile_round.py writes
@@ -441,6 +470,8 @@ def main():
         out["sweep"] = sweep()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, gsd)
+        if "train_step" in out:
+            out["train_step"]["cpu_baseline"] = cpu_train_baseline(sd)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
