@@ -60,3 +60,13 @@ def test_struct_layout_matches_c(tmp_path, name):
     assert out[0] == ctypes.sizeof(cls)
     for f, off in zip(fields, out[1:]):
         assert getattr(cls, f).offset == off, f
+
+
+def test_partial_sum_chunk_sizes_match_the_host_code():
+    """training.py sizes its partial-sum buffers as ceil(T / 32) rows per chunk; the library says the same (pure host
+    functions, no GPU needed)"""
+    from serenade_amd import _lib
+    h = _lib.lib()
+    for T in (1, 31, 32, 33, 1000, 4352):
+        assert h.srn_rowln_chunks(T) == (T + 31) // 32 == h.srn_gn_chunks(T)
+    assert 1 <= h.srn_sumsq_blocks(10) <= h.srn_sumsq_blocks(84_287_728) <= 1024
