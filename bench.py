@@ -70,13 +70,11 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
     loss0 = loss = None
     for it in range(steps + 1):  # one warm-up
         e = [ev() for _ in range(4)]
-        model.zero_grad()
         e[0].record()
         ret = model(x, lens, logmel, midi, lft)
         loss = ret["cfm_loss"] + ret["prior_loss"]
         e[1].record()
-        loss.backward()
-        sync.finish()
+        model.backward(loss, sync)  # one rank: autograd.grad + one multi-tensor copy; several: hooks + bucketed all-reduce
         e[2].record()
         opt.step()
         e[3].record()

@@ -623,6 +623,19 @@ class TrainSerenade:
     def zero_grad(self):
         self.store.zero_grad()
 
+    def backward(self, loss, sync=None):
+        """gradients of `loss` into the flat buffer, all-reduced if `sync` spans several ranks.  With a GradSync that
+        overlaps: zero_grad() + `loss.backward()`, whose per-parameter hooks launch the bucketed all-reduce while
+        backward is still running, + sync.finish().  Otherwise one `torch.autograd.grad` + one multi-tensor copy that
+        OVERWRITES the buffer -- no zero fill, none of the 262 per-parameter accumulation kernels -- then sync.finish()."""
+        if sync is not None and sync._hooks:
+            self.zero_grad()
+            loss.backward()
+        else:
+            self.store.backward_into_flat(loss)
+        if sync is not None:
+            sync.finish()
+
     def state_dict(self):
         sd = self.store.state_dict()
         sd.update({k: v.clone() for k, v in self.buffers.items()})
