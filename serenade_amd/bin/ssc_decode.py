@@ -186,8 +186,13 @@ class DecodeJob:
         else:
             mels = [self.model.inference(x, lengths, score, loud, r["cvec"], r["lens"], r["mel"], r["score"], r["loud"])
                     for _, r, _ in jobs]
-        for (style, _, lf0), mel in zip(jobs, mels):
-            wave, _ = self.vocoder.decode(mel.squeeze(0) if mel.dim() == 3 else mel)
+        mels = [m.squeeze(0) if m.dim() == 3 else m for m in mels]
+        if self.args.batch_styles and len(mels) > 1:
+            # all styles of an utterance have the source's length: one vocoder batch (no cross-item arithmetic in HiFi-GAN)
+            waves = list(self.vocoder.decode_batch(torch.stack(mels)))
+        else:
+            waves = [self.vocoder.decode(m)[0] for m in mels]
+        for (style, _, lf0), wave in zip(jobs, waves):
             write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0)
             write_wav_pcm16(os.path.join(out, f"{utt}_{style}.wav"), wave.cpu().numpy(), self.sr)
             done += x.shape[1]
