@@ -282,21 +282,22 @@ def test_gradient_allreduce_over_rccl_group_of_one(dev):
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-2000:]
 
 
-def test_captured_step_equals_eager_step(dev):
+@pytest.mark.parametrize("B,L,lrs", [(4, 512, (0.0, 8e-4)), (8, 1024, (0.0,))])
+def test_captured_step_equals_eager_step(dev, B, L, lrs):
     """GraphedStep: the whole-model step captured as a hipGraph (device-side infill segment, clip factor and Adam bias
     corrections).  (a) With the weights frozen (lr = 0) every replay reproduces the eager step's losses and ALL
     gradients on three different batches -- torch's own multi-block reductions returned stale values from the second
     replay on, which is why the step routes them through rocBLAS / srn_sumsq; (b) with the optimizer on, losses and
     gradient norms track the eager run."""
-    w = serenade_weights()
-    B, L = 4, 512  # large enough for multi-block reductions
+    w = serenade_weights()  # sizes large enough for multi-block reductions
     g = torch.Generator().manual_seed(8)
-    batches = [[torch.randn(B, L, 768, generator=g).to(dev), torch.tensor([512, 400, 333, 512]).to(dev),
+    lens0 = torch.tensor([L - (L // 5) * (i % 3) for i in range(B)])
+    batches = [[torch.randn(B, L, 768, generator=g).to(dev), lens0.to(dev),
                 torch.randn(B, L, 80, generator=g).to(dev), torch.randn(B, L, 1, generator=g).to(dev),
                 torch.randn(B, L, 1, generator=g).to(dev)] for _ in range(3)]
     t, z = torch.rand(B, 1, 1, generator=g).to(dev), torch.randn(B, 80, L, generator=g).to(dev)
-    segs = [(100, 200), (0, 255), (300, 60)]
-    for lr in (0.0, 8e-4):
+    segs = [(L // 5, 2 * L // 5), (0, L // 2 - 1), (3 * L // 5, L // 8)]
+    for lr in lrs:
         eager = training.TrainSerenade(w, dev, dropout=0.0)
         opt_e = training.AdamW(eager, lr=lr, weight_decay=0.0 if lr == 0.0 else 0.01)
         cap = training.TrainSerenade(w, dev, dropout=0.0)
@@ -322,6 +323,8 @@ def test_captured_step_equals_eager_step(dev):
                 for k in cap.params:
                     ref = eager.params[k].grad
                     if ref.abs().max() > 1e-7:  # not the mathematically-zero key bias of the token attention
-                        assert rel(cap.params[k].grad.cpu(), ref.cpu()) < 1e-4, (i, k)
+                        # MIOpen's conv2d weight gradients (the GST's library path) are not run-to-run reproducible
+                        tol_k = 2e-3 if k.startswith("gst.ref_enc.convs.") else 1e-4
+                        assert rel(cap.params[k].grad.cpu(), ref.cpu()) < tol_k, (i, k)
         if lr == 0.0:
             assert torch.equal(cap.flat, start)
