@@ -293,6 +293,14 @@ int srn_gn_mish_bwd_apply(const float* h, const float* dy, const float* mean, co
                           const float* beta, const float* gsum, const int32_t* lens, float* dh, int B, int T, int C,
                           int groups, void* stream);
 int srn_gn_chunks(int T);
+/* (mean, rstd)[b][g] of GroupNorm from the producing conv's 32 x 32 tile sums (SrnConvParams.gn_partials), statistics
+ * over the padded length T: what srn_gn_mish_apply uses internally, kept for the backward pass. */
+int srn_gn_stats(const float* partials, float* mean, float* rstd, int B, int T, int C, int groups, float eps,
+                 void* stream);
+/* col (B, 2, C) = sum over chunks of a (B, n_chunk, 2, C) partial-sum buffer of the kernels above; with gsum != NULL
+ * also gsum (B, groups, 2) = per-group sums of gamma * col (step between srn_gn_mish_bwd_partial and _apply). */
+int srn_chunk_colsum(const float* partial, const float* gamma, float* col, float* gsum, int B, int n_chunk, int C,
+                     int groups, void* stream);
 /* softmax backward in place on dp: dp <- scale * p o (dp - rowsum(dp o p)); rows of L with stride ld. */
 int srn_softmax_bwd(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream);
 /* GEGLU (transformer.py:120-146): hg (rows, 2 inner) = [h | g]; a = h * gelu_erf(g); backward dhg from da. */

@@ -81,6 +81,8 @@ _SIGS = {
     "srn_gn_mish_bwd_partial": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
     "srn_gn_mish_bwd_apply": (c_int, [_P] * 9 + [c_int] * 4 + [_P]),
     "srn_gn_chunks": (c_int, [c_int]),
+    "srn_gn_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    "srn_chunk_colsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "srn_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P]),
     "srn_geglu_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "srn_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

@@ -269,6 +269,63 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_apply_kernel(
   }
 }
 
+// ---- GroupNorm statistics from the conv epilogue's 32 x 32 tile sums: (mean, rstd)[b][g], fp64 accumulation,
+// statistics over the padded length T (the arithmetic of norm_act.hip's group_stats, kept for the backward pass)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ partials, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int T, int C, int groups, float eps) {
+  const int b = blockIdx.x;
+  const int gn_mt = (T + 31) / 32, gn_nt = C / 32, nt_per_g = (C / groups) / 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* base = partials + (int64_t)b * gn_mt * gn_nt * 2;
+  const int per_g = gn_mt * nt_per_g;
+  for (int g = wave; g < groups; g += 4) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = lane; e < per_g; e += 64) {
+      const int mt = e / nt_per_g;
+      const int nt = g * nt_per_g + (e - mt * nt_per_g);
+      const float2 v = *reinterpret_cast<const float2*>(base + ((int64_t)mt * gn_nt + nt) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) {
+      const double cnt = (double)T * (double)(C / groups);
+      const double m = s1 / cnt;
+      double var = s2 / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      mean[b * groups + g] = (float)m;
+      rstd[b * groups + g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+}
+
+// ---- column sums of per-chunk partial sums: col[b][k][c] = sum_chunk partial[b][chunk][k][c], and (optional) the
+// per-group sums of gamma * col that the GroupNorm backward needs: gsum[b][g][k]
+__global__ __launch_bounds__(256) void chunk_colsum_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                           float* __restrict__ col, float* __restrict__ gsum, int n_chunk,
+                                                           int C, int groups) {
+  __shared__ float cs[2 * MAXV * 256];  // gamma * column sums, for the per-group sums (fixed summation order)
+  const int b = blockIdx.x;
+  const float* p = partial + (int64_t)b * n_chunk * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunk; ++ch) s += p[((int64_t)ch * 2 + k) * C + c];
+    col[((int64_t)b * 2 + k) * C + c] = s;
+    if (gsum) cs[i] = s * gamma[c];
+  }
+  if (gsum == nullptr) return;
+  __syncthreads();
+  const int cpg = C / groups;
+  if (threadIdx.x < 2 * groups) {
+    const int k = threadIdx.x / groups, g = threadIdx.x - k * groups;
+    float s = 0.f;
+    for (int c = 0; c < cpg; ++c) s += cs[k * C + g * cpg + c];
+    gsum[((int64_t)b * groups + g) * 2 + k] = s;
+  }
+}
+
 // ---- softmax backward in place: dp <- scale * p o (dp - sum_j dp_j p_j); one wave per row of L (row stride ld)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp,
                                                           int64_t rows, int L, int ld, float scale) {
@@ -490,6 +547,29 @@ extern "C" int srn_sumsq_blocks(int64_t n) { return (int)grid_for((n + 7) / 8, 1
 extern "C" int srn_sumsq(const float* g, int64_t n, double* partial, void* stream) {
   SRN_CHECK_ARG(g && partial && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "sumsq: bad args");
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)srn_sumsq_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_gn_stats(const float* partials, float* mean, float* rstd, int B, int T, int C, int groups, float eps,
+                            void* stream) {
+  SRN_CHECK_ARG(partials && mean && rstd && B > 0 && T > 0, "gn_stats: bad args");
+  SRN_CHECK_ARG(C > 0 && groups > 0 && C % groups == 0 && (C / groups) % 32 == 0, "gn_stats: C=%d groups=%d unsupported", C,
+                groups);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partials, mean, rstd, T, C,
+                     groups, eps);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_chunk_colsum(const float* partial, const float* gamma, float* col, float* gsum, int B, int n_chunk, int C,
+                                int groups, void* stream) {
+  SRN_CHECK_ARG(partial && col && B > 0 && n_chunk > 0 && C > 0, "chunk_colsum: bad args");
+  SRN_CHECK_ARG(C <= 256 * MAXV, "chunk_colsum: C=%d unsupported", C);
+  SRN_CHECK_ARG(gsum == nullptr || (gamma != nullptr && groups > 0 && groups <= 128 && C % groups == 0),
+                "chunk_colsum: bad group arguments");
+  hipLaunchKernelGGL(chunk_colsum_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, gamma, col, gsum,
+                     n_chunk, C, groups);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -184,12 +184,11 @@ def pack_conv(w, c_pad=None):
 # =====================================================================================================================
 def _gn_stats(part, T, C, groups, eps):
     """(mean, rstd) (B, groups) fp32 from the conv epilogue's 32 x 32 tile sums; statistics over the padded length"""
-    B, mt, nt, _ = part.shape
-    s = part.double().sum(1).view(B, groups, nt // groups, 2).sum(2)
-    cnt = float(T) * (C // groups)
-    mean = s[..., 0] / cnt
-    var = (s[..., 1] / cnt - mean * mean).clamp_min(0.0)
-    return mean.float().contiguous(), (1.0 / torch.sqrt(var + eps)).float().contiguous()
+    B = part.shape[0]
+    mean = torch.empty(B, groups, device=part.device, dtype=torch.float32)
+    rstd = torch.empty(B, groups, device=part.device, dtype=torch.float32)
+    _call("srn_gn_stats", part, mean, rstd, B, T, C, groups, eps)
+    return mean, rstd
 
 
 class _GNMish(torch.autograd.Function):
@@ -212,9 +211,11 @@ class _GNMish(torch.autograd.Function):
         nch = (T + 31) // 32
         part = torch.empty(B, nch, 2, C, device=h.device, dtype=torch.float32)
         _call("srn_gn_mish_bwd_partial", h, dy, mean, rstd, gamma, beta, lens, part, B, T, C, G)
-        col = part.sum(1)  # (B, 2, C): sum_t dg, sum_t dg * xhat
-        dbeta, dgamma = col[:, 0].sum(0), col[:, 1].sum(0)
-        gsum = (col * gamma).view(B, 2, G, C // G).sum(-1).transpose(1, 2).contiguous()  # (B, G, 2)
+        col = torch.empty(B, 2, C, device=h.device, dtype=torch.float32)  # sum_t dg, sum_t dg * xhat
+        gsum = torch.empty(B, G, 2, device=h.device, dtype=torch.float32)
+        _call("srn_chunk_colsum", part, gamma, col, gsum, B, nch, C, G)
+        dcol = col.sum(0)
+        dbeta, dgamma = dcol[0], dcol[1]
         dh = torch.empty_like(h)
         _call("srn_gn_mish_bwd_apply", h, dy, mean, rstd, gamma, beta, gsum, lens, dh, B, T, C, G)
         return dh, None, dgamma, dbeta, None, None, None
@@ -248,10 +249,12 @@ class _RowLN(torch.autograd.Function):
         part = torch.empty(B, nch, 2, C, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         _call("srn_rowln_bwd", x, dy, m, C if ctx.per_b else 0, dx, part, B, T, C, ctx.eps)
-        col = part.sum(1)  # (B, 2, C)
+        col = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
+        _call("srn_chunk_colsum", part, None, col, None, B, nch, C, 1)
         if ctx.per_b:
             return dx, col[:, 0].contiguous(), col[:, 1].contiguous(), None
-        return dx, col[:, 0].sum(0), col[:, 1].sum(0), None
+        dcol = col.sum(0)
+        return dx, dcol[0], dcol[1], None
 
 
 def row_ln(x, m, a, eps=1e-5):

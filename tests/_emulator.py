@@ -358,6 +358,18 @@ def emul_call(name, a):
             A = gs[:, :, 0].reshape(B, 1, G).repeat_interleave(C // G, dim=2) / n
             Bq = gs[:, :, 1].reshape(B, 1, G).repeat_interleave(C // G, dim=2) / n
             _v(out, B * T * C).reshape(B, T, C)[:] = rs * (dg * gamma - A - xh * Bq)
+    elif name == "srn_gn_stats":
+        part, mean, rstd, B, T, C, G, eps = a
+        mv, rv = _v(mean, B * G).reshape(B, G), _v(rstd, B * G).reshape(B, G)
+        for b in range(B):
+            mv[b], rv[b] = _group_stats(part, b, T, C, G, eps)
+    elif name == "srn_chunk_colsum":
+        part, gamma, col, gsum, B, nch, C, G = a
+        pv = _v(part, B * nch * 2 * C).reshape(B, nch, 2, C)
+        cv = _v(col, B * 2 * C).reshape(B, 2, C)
+        cv[:] = pv.sum(1)
+        if gsum is not None:
+            _v(gsum, B * G * 2).reshape(B, G, 2)[:] = (cv * gamma).reshape(B, 2, G, C // G).sum(-1).transpose(1, 2)
     elif name == "srn_softmax_bwd":
         pm, dp, rows, L, ld, scale = a
         pv = _v(pm, rows * ld).reshape(rows, ld)[:, :L]
