@@ -201,7 +201,7 @@ def test_whole_model_gradients_match_the_reference(dev, golden):
     (ret["cfm_loss"] + ret["prior_loss"]).backward()
     torch.cuda.synchronize()
     check_whole_model(g, {k: v.detach().cpu() for k, v in ret.items()},
-                      {k: v.grad.detach().cpu() for k, v in model.params.items()})
+                      {k: v.grad.detach().cpu() for k, v in model.params.items()}, gst_conv_tol=2e-3)
     assert rel(model.buffers["gst.ref_enc.convs.16.running_var"].cpu(), torch.from_numpy(g["bn_var"])) < 1e-4
 
 

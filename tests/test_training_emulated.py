@@ -131,7 +131,7 @@ def _full_case(g):
                 draws={"uniform": float(g["uniform"]), "seg_start": int(g["seg_start"]), "t": t("t"), "z": t("z")})
 
 
-def check_whole_model(g, ret, grads, tol=3e-4):
+def check_whole_model(g, ret, grads, tol=3e-4, gst_conv_tol=None):
     for k in ("cfm_loss", "prior_loss"):
         assert abs(float(ret[k].detach()) - float(g[k])) < 2e-5 * abs(float(g[k])), k
     assert rel(ret["gauss_mel"].detach().cpu(), torch.from_numpy(g["gauss_mel"])) < 1e-4
@@ -144,7 +144,9 @@ def check_whole_model(g, ret, grads, tol=3e-4):
         if ref.abs().max() < 1e-8:  # mathematically zero (the key bias of the token attention shifts every score alike)
             assert got.abs().max() < 1e-8, key
         else:
-            assert rel(got, ref) < tol, key
+            # gst_conv_tol (GPU): MIOpen's Conv2d weight gradients are not run-to-run reproducible at the 1e-4 level
+            t = gst_conv_tol if (gst_conv_tol and key[2:].startswith("gst.ref_enc.convs.")) else tol
+            assert rel(got, ref) < t, key
     total = math.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
     assert abs(total - float(g["grad_norm"])) < 2e-4 * float(g["grad_norm"])
 
