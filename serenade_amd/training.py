@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import _lib, ops
 from .ops import ConvOp
 
-__all__ = ["Estimator", "TrainSerenade", "ParamStore", "GraphedStep", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
+__all__ = ["Estimator", "TrainSerenade", "ParamStore", "GraphedStep", "MultiStepLR", "save_checkpoint", "load_checkpoint", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
 
 
 def _require_cuda(t, what):
@@ -883,6 +883,65 @@ class AdamW:
             _call("srn_adamw", self.est.flat, g, self.m, self.v, g.numel(), self.lr, self.betas[0], self.betas[1],
                   self.eps, self.wd, self.steps, scale)
         return norm
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR for `AdamW` above (conf/serenade.yaml:66-70: gamma 0.5 at step 100 000):
+    call step() once per optimizer step, as trainers/ssc.py:96 does."""
+
+    def __init__(self, opt, milestones, gamma=0.5):
+        self.opt, self.milestones, self.gamma = opt, sorted(int(m) for m in milestones), float(gamma)
+        self.base_lr, self.last_epoch = opt.lr, 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
+
+    def state_dict(self):
+        return {"milestones": list(self.milestones), "gamma": self.gamma, "base_lr": self.base_lr,
+                "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.milestones, self.gamma = [int(m) for m in sd["milestones"]], float(sd["gamma"])
+        self.base_lr, self.last_epoch = float(sd["base_lr"]), int(sd["last_epoch"])
+        self.opt.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
+
+
+def save_checkpoint(path, model, opt, scheduler=None, steps=0, epochs=0):
+    """the reference's checkpoint layout (trainers/base.py:91-111): {"model": state_dict, "optimizer", "scheduler",
+    "steps", "epochs"}.  "model" loads into the reference's / this package's `Serenade`; the optimizer entry holds the
+    two flat moment buffers with the parameter layout (name -> (offset, size)) they follow."""
+    import os
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save({"model": {k: v.cpu() for k, v in model.state_dict().items()},
+                "optimizer": {"m": opt.m.cpu(), "v": opt.v.cpu(), "steps": opt.steps, "lr": opt.lr, "betas": opt.betas,
+                              "eps": opt.eps, "weight_decay": opt.wd, "spans": dict(model.spans)},
+                "scheduler": None if scheduler is None else scheduler.state_dict(), "steps": int(steps),
+                "epochs": int(epochs)}, path)
+
+
+def load_checkpoint(path, model, opt=None, scheduler=None, load_only_params=False):
+    """trainers/base.py:113-130: restores the weights (and BatchNorm statistics) in place; with an optimizer also its
+    moments and step count.  Returns (steps, epochs)."""
+    ck = torch.load(path, map_location="cpu")
+    with torch.no_grad():
+        for k, v in ck["model"].items():
+            if k in model.params:
+                model.params[k].copy_(v)
+            elif k in getattr(model, "buffers", {}):
+                model.buffers[k].copy_(v)
+            else:
+                raise KeyError(f"checkpoint tensor {k} is not a tensor of this model")
+    if load_only_params or opt is None:
+        return int(ck.get("steps", 0)), int(ck.get("epochs", 0))
+    o = ck["optimizer"]
+    if dict(o["spans"]) != dict(model.spans):
+        raise ValueError("optimizer state was saved for a different parameter layout")
+    opt.m.copy_(o["m"]), opt.v.copy_(o["v"])
+    opt.steps, opt.lr = int(o["steps"]), float(o["lr"])
+    if scheduler is not None and ck.get("scheduler") is not None:
+        scheduler.load_state_dict(ck["scheduler"])
+    return int(ck["steps"]), int(ck["epochs"])
 
 
 class GraphedStep:

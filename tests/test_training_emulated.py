@@ -173,3 +173,42 @@ def test_whole_model_gradients_match_the_reference(golden):
     # BatchNorm running statistics moved like nn.BatchNorm2d's (momentum 0.1)
     assert rel(model.buffers["gst.ref_enc.convs.16.running_mean"], torch.from_numpy(g["bn_mean"])) < 1e-4
     assert rel(model.buffers["gst.ref_enc.convs.16.running_var"], torch.from_numpy(g["bn_var"])) < 1e-4
+
+
+def test_checkpoint_resume_and_lr_schedule(tmp_path):
+    """trainers/base.py:91-130 layout: train 2 steps, save, train 2 more; a fresh model + optimizer resumed from the
+    file reproduces those 2 steps bit for bit; MultiStepLR halves the rate at its milestone"""
+    w = serenade_weights()
+    keep = [k for k in w if not k.startswith("cfm_decoder.estimator.")]  # encoder + GST are enough for the file format
+    small = {k: w[k] for k in keep}
+
+    def fake_step(model, opt, sched, i):
+        model.zero_grad()
+        gg = torch.Generator().manual_seed(100 + i)
+        for p in model.params.values():
+            p.grad.copy_(torch.randn(p.shape, generator=gg))
+        opt.step()
+        sched.step()
+
+    with _emulator.installed():
+        a = training.ParamStore(small, torch.device("cpu"), skip=[k for k in small if "running_" in k or "num_batches" in k])
+        a.buffers = {}
+        oa = training.AdamW(a, lr=1e-3)
+        sa = training.MultiStepLR(oa, [3], gamma=0.5)
+        for i in range(2):
+            fake_step(a, oa, sa, i)
+        training.save_checkpoint(str(tmp_path / "ck" / "checkpoint-2steps.pkl"), a, oa, sa, steps=2, epochs=1)
+        for i in range(2, 4):
+            fake_step(a, oa, sa, i)
+        assert oa.lr == 5e-4  # milestone 3 passed
+        b = training.ParamStore(small, torch.device("cpu"), skip=[k for k in small if "running_" in k or "num_batches" in k])
+        b.buffers = {}
+        ob = training.AdamW(b, lr=123.0)
+        sb = training.MultiStepLR(ob, [999])
+        steps, epochs = training.load_checkpoint(str(tmp_path / "ck" / "checkpoint-2steps.pkl"), b, ob, sb)
+        assert (steps, epochs) == (2, 1) and ob.steps == 2 and ob.lr == 1e-3 and sb.milestones == [3]
+        for i in range(2, 4):
+            fake_step(b, ob, sb, i)
+    assert torch.equal(a.flat, b.flat) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v) and ob.lr == 5e-4
+    ck = torch.load(str(tmp_path / "ck" / "checkpoint-2steps.pkl"))
+    assert set(ck) == {"model", "optimizer", "scheduler", "steps", "epochs"}
