@@ -57,3 +57,22 @@ def test_strip_is_selected_and_matches_tiled(dev):
                    out_bs=T * C, ld_out=C, taps=ops.conv_taps(k, 1), no_halo=nh)()
         outs.append(out.cpu())
     assert (outs[0] - outs[1]).abs().max() <= 1e-5 * outs[1].abs().max()
+
+
+@pytest.mark.parametrize("force,cin,n,k,dil", [(4, 32, 32, 11, 5), (4, 64, 64, 7, 3), (2, 128, 128, 11, 3), (2, 256, 256, 7, 1),
+                                               (1, 128, 64, 3, 1)])
+def test_forced_kernels_against_torch_conv1d(dev, force, cin, n, k, dil):
+    """strip (4), halo (2) and tiled (1) kernels against torch.nn.functional directly -- not only the ABI emulator:
+    the HiFi-GAN residual-unit conv `conv1d(leaky_relu(x), w, b, dilation)` + residual (residual_block.py:243-258)"""
+    import torch.nn.functional as F
+    serenade_amd.set_precision("fp32")
+    B, T = 2, 1500
+    x, w, b = rnd(B, T, cin, seed=1), rnd(n, cin, k, seed=2) * 0.1, rnd(n, seed=3)
+    res = rnd(B, T, n, seed=4)
+    ref = F.conv1d(F.leaky_relu(x, 0.1).transpose(1, 2), w, b, dilation=dil, padding=(k - 1) // 2 * dil).transpose(1, 2) + res
+    out = torch.zeros(B, T, n, device=dev)
+    ops.ConvOp(in0=x.to(dev), w=ops.pack_conv_weight(w).to(dev), bias=b.to(dev), out=out, n_batch=B, T_in=T, T_out=T,
+               C_in=cin, N=n, in0_bs=T * cin, ld_in0=cin, ldw=k * cin, out_bs=T * n, ld_out=n, taps=ops.conv_taps(k, dil),
+               pro_act=_lib.ACT_LEAKY, pro_slope=0.1, res=res.to(dev), res_mode=_lib.RES_ADD, res_bs=T * n, ld_res=n,
+               no_halo=force)()
+    assert ((out.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-6
