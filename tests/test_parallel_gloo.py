@@ -122,3 +122,55 @@ def test_gradient_allreduce_buckets_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     assert n_buckets >= 3
+
+
+def _est_worker(rank, world, port, q):
+    """the real backward graph: every rank differentiates its own batch through the (emulated) estimator with the
+    bucketed overlap hooks on; the result must be the mean of the ranks' stand-alone gradients"""
+    from serenade_amd import training
+    from tests import _emulator
+    from tests._weights import serenade_weights, sub
+    from tests.test_training_emulated import _case
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    cases = [_case(B=1, L=16, lens=(16,), seed=40 + r) for r in range(world)]
+    with _emulator.installed():
+        def grads_of(case, sync_factory):
+            est = training.Estimator(w, torch.device("cpu"))
+            sync = sync_factory(est)
+            x1, mask, mu, spk, mask_l, t, z = case
+            mask_l = mask.clone()
+            mask_l[:, :, :3] = 0
+            mask_l[:, :, 11:] = 0
+            loss, _ = training.cfm_loss(est, x1, mask, mu, spk, mask_l, draws={"t": t, "z": z})
+            est.zero_grad()
+            loss.backward()
+            if sync is not None:
+                sync.finish()
+            return est, sync
+        est, sync = grads_of(cases[rank], lambda e: training.GradSync(e, bucket_bytes=32 << 20))
+        assert len(sync.buckets) >= 3 and sync.launched == len(sync.buckets)
+        if rank == 0:
+            alone = [grads_of(c, lambda e: None)[0].flat_grad for c in cases]
+            want = sum(alone) / world
+            err = ((est.flat_grad - want).abs().max() / want.abs().max()).item()
+            q.put(err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_estimator_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_est_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert err < 1e-6
