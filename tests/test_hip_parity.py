@@ -597,3 +597,25 @@ def test_hipgraph_replay_is_bitwise_the_eager_run(dev, model, voc):
     finally:
         ops.set_graphs(False)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_bf16x6_is_as_accurate_as_the_fp32_mfma(dev, precision):
+    """the claim behind the `fp32_emulated_bf16x6_mode` bench line: against an fp64 reference a K = 2048 contraction in
+    bf16x6 (exact hi + mid + lo split, 6 bf16 MFMAs per product, fp32 accumulate) is no less accurate than the exact-fp32
+    MFMA chain (both are limited by their fp32 accumulation order), and ~10x more accurate than bf16x3"""
+    if precision != "fp32":
+        pytest.skip("one arm: the test sets the modes itself")
+    M, N, K = 512, 512, 2048
+    x, w = rnd(1, M, K, seed=11), rnd(N, K, seed=12)
+    ref = (x[0].double() @ w.double().t())
+    errs = {}
+    for mode in ("fp32", "bf16x6", "bf16x3"):
+        serenade_amd.set_precision(mode)
+        out = torch.zeros(1, M, N, device=dev)
+        ops.ConvOp(in0=x.to(dev), w=w.to(dev), out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, in0_bs=M * K, ld_in0=K,
+                   ldw=K, out_bs=M * N, ld_out=N)()
+        d = (out[0].cpu().double() - ref).abs()
+        errs[mode] = (d.max().item() / ref.abs().max().item(), d.pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item())
+    serenade_amd.set_precision("fp32")
+    assert errs["bf16x6"][0] <= 1.5 * errs["fp32"][0] and errs["bf16x6"][1] <= 1.5 * errs["fp32"][1], errs
+    assert errs["bf16x6"][1] < 1e-6 and errs["bf16x3"][1] > 3 * errs["bf16x6"][1], errs
