@@ -13,7 +13,8 @@ PCM) and the transposed F0 contour as dataset `lf0` of `U_S.h5` (`.npz` when the
 (utterance, style) pair is one B = 1 call, like the reference: GroupNorm statistics of the estimator run over an
 item's padded length (decoder.py:71-77), so naive padding into a batch would change the output.  `--batch-styles`
 converts all styles of an utterance in one *exact* ragged batch (`Serenade.inference_ragged`: per-item GroupNorm
-statistics, per-item reflection padding, per-item prompt / source offsets), whose results equal the loop's.  With
+statistics, per-item reflection padding, per-item prompt / source offsets), whose results equal the loop's;
+`--batch-utterances N` extends the batch over N source utterances of different lengths.  With
 `torchrun --nproc-per-node N` the utterance list is split contiguously over the ranks (one GPU each).
 """
 import argparse
@@ -82,6 +83,9 @@ def build_parser():
                    help="(MI355X build only) convert all reference styles of an utterance in ONE ragged batch "
                         "(Serenade.inference_ragged: every item is computed exactly as its own B = 1 call, so the "
                         "outputs equal the default style-by-style loop) -- fills the GPU instead of running B = 1")
+    p.add_argument("--batch-utterances", type=int, default=1,
+                   help="(MI355X build only) convert this many source utterances, with all their styles, per exact "
+                        "ragged batch (implies --batch-styles); outputs equal the one-by-one loop")
     return p
 
 
@@ -157,19 +161,18 @@ class DecodeJob:
                     loud=self._t(self._minmax(raw["loud"], "loud")).unsqueeze(0), wave=raw["wave"], f0=raw["f0"])
 
     # ---- the loop ------------------------------------------------------------------------------------------
-    def convert(self, item):
-        """all styles of one source utterance; returns the number of converted frames"""
+    def _jobs(self, item):
+        """host side of one source utterance: writes the ground-truth / reference audio, returns the (utterance,
+        style) conversions to run: (utt, style, x, score, loud, prompt tensors, transposed F0)"""
         out = self.args.outdir
         utt = item["utt_id"]
         logging.info(f"utterance {utt}")
         write_wav_pcm16(os.path.join(out, f"{utt}_gt.wav"), item["audio"], self.sr)
         x = self._t(item["hubert"]).unsqueeze(0)
-        lengths = torch.tensor([x.shape[1]], dtype=torch.long)
         score, loud = self._t(item["score"]).unsqueeze(0), self._t(item["loud"]).unsqueeze(0)
         if self.styles is None:  # drawn once, for the first utterance, then kept (ssc_decode.py:375-376)
             self.styles = get_random_ref_style(self.args.dumpdir, utt, self.ext)
-        done = 0
-        jobs = []  # (style, prompt tensors, transposed F0) in style order
+        jobs = []
         for style, path in self.styles.items():
             if style in utt:  # a prompt of the utterance's own style would be a reconstruction
                 continue
@@ -179,32 +182,59 @@ class DecodeJob:
             # NB: linear_midi_shift edits item["lf0"] in place, so later styles start from the shifted contour --
             # the reference behaves the same way (ssc_decode.py:424); snapshot what it would write for this style
             lf0 = linear_midi_shift(item["lf0"], ref["f0"]).astype(np.float32)
-            jobs.append((style, ref, lf0))
-        if self.args.batch_styles and len(jobs) > 1:
+            jobs.append((utt, style, x, score, loud, ref, lf0))
+        return jobs
+
+    def _run_jobs(self, jobs, batched):
+        """convert and write a list of jobs; batched: ONE exact ragged batch for the model (every item = its own B = 1
+        call) and one vocoder batch per distinct length (HiFi-GAN has no cross-item arithmetic, but its edge padding
+        sits at the tensor's end, so only equal lengths share a batch)"""
+        if not jobs:
+            return 0
+        out = self.args.outdir
+        if batched and len(jobs) > 1:
             mels = self.model.inference_ragged(
-                [(x[0], score[0], loud[0], r["cvec"][0], r["mel"][0], r["score"][0], r["loud"][0]) for _, r, _ in jobs])
+                [(x[0], sc[0], ld[0], r["cvec"][0], r["mel"][0], r["score"][0], r["loud"][0])
+                 for _, _, x, sc, ld, r, _ in jobs])
+            waves = [None] * len(jobs)
+            by_len = {}
+            for i, m in enumerate(mels):
+                by_len.setdefault(m.shape[0], []).append(i)
+            for idx in by_len.values():
+                for i, w in zip(idx, self.vocoder.decode_batch(torch.stack([mels[i] for i in idx]))):
+                    waves[i] = w
         else:
-            mels = [self.model.inference(x, lengths, score, loud, r["cvec"], r["lens"], r["mel"], r["score"], r["loud"])
-                    for _, r, _ in jobs]
-        mels = [m.squeeze(0) if m.dim() == 3 else m for m in mels]
-        if self.args.batch_styles and len(mels) > 1:
-            # all styles of an utterance have the source's length: one vocoder batch (no cross-item arithmetic in HiFi-GAN)
-            waves = list(self.vocoder.decode_batch(torch.stack(mels)))
-        else:
-            waves = [self.vocoder.decode(m)[0] for m in mels]
-        for (style, _, lf0), wave in zip(jobs, waves):
+            waves = []
+            for _, _, x, sc, ld, r, _ in jobs:
+                lengths = torch.tensor([x.shape[1]], dtype=torch.long)
+                mel = self.model.inference(x, lengths, sc, ld, r["cvec"], r["lens"], r["mel"], r["score"], r["loud"])
+                waves.append(self.vocoder.decode(mel.squeeze(0) if mel.dim() == 3 else mel)[0])
+        done = 0
+        for (utt, style, x, _, _, _, lf0), wave in zip(jobs, waves):
             write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0)
             write_wav_pcm16(os.path.join(out, f"{utt}_{style}.wav"), wave.cpu().numpy(), self.sr)
             done += x.shape[1]
         return done
 
+    def convert(self, item):
+        """all styles of one source utterance; returns the number of converted frames"""
+        return self._run_jobs(self._jobs(item), self.args.batch_styles)
+
     def run(self):
         rank, world = parallel.rank_world()
         lo, hi = parallel.shard_range(len(self.dataset), rank, world)
         frames, t0 = 0, time.time()
+        n_utt = max(1, int(self.args.batch_utterances))
         with torch.no_grad():
-            for i in range(lo, hi):
-                frames += self.convert(self.dataset[i])
+            if n_utt == 1:
+                for i in range(lo, hi):
+                    frames += self.convert(self.dataset[i])
+            else:  # several utterances (all their styles) per exact ragged batch
+                for i0 in range(lo, hi, n_utt):
+                    jobs = []
+                    for i in range(i0, min(i0 + n_utt, hi)):
+                        jobs += self._jobs(self.dataset[i])
+                    frames += self._run_jobs(jobs, True)
         dt = max(time.time() - t0, 1e-9)
         logging.info(f"rank {rank}/{world}: {frames} frames in {dt:.2f} s = {frames / dt:.1f} frames/s")
         return frames

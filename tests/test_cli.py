@@ -135,6 +135,7 @@ def _two_style_tree(tmp_path):
     for d in ("dump", "exp", "ref", "voc"):
         (tmp_path / d).mkdir()
     np.savez(tmp_path / "dump" / "EN_spk1_song_Control_Group_0001.npz", **_feats(rng, 20))
+    np.savez(tmp_path / "dump" / "EN_spk1_song_Control_Group_0002.npz", **_feats(rng, 27))
     np.savez(tmp_path / "ref" / "breathy.npz", **_feats(rng, 13))
     np.savez(tmp_path / "ref" / "falsetto.npz", **_feats(rng, 18))
     scaler = {"logmel": StandardScaler().fit(rng.standard_normal((50, 80))),
@@ -165,13 +166,14 @@ def _batch_styles_case(tmp_path, on_gpu):
     argv = _two_style_tree(tmp_path)
     outs = {}
     with (contextlib.nullcontext() if on_gpu else _emulator.installed()):
-        for name, extra in (("loop", []), ("batch", ["--batch-styles"])):
+        for name, extra in (("loop", []), ("batch", ["--batch-styles"]), ("utts", ["--batch-utterances", "2"])):
             torch.manual_seed(7)
             ssc_decode.main(argv + ["--outdir", str(tmp_path / name)] + extra)
             outs[name] = sorted(os.listdir(tmp_path / name))
-    assert outs["loop"] == outs["batch"] and len(outs["loop"]) == 7  # gt + 2 x (reference, wav, lf0)
-    for f in outs["loop"]:
-        a, b = tmp_path / "loop" / f, tmp_path / "batch" / f
+    # 2 utterances x (gt + 2 x (wav, lf0)) + 2 reference wavs
+    assert outs["loop"] == outs["batch"] == outs["utts"] and len(outs["loop"]) == 12
+    for f, other in [(f, o) for f in outs["loop"] for o in ("batch", "utts")]:
+        a, b = tmp_path / "loop" / f, tmp_path / other / f
         if f.endswith(".wav"):
             with wavmod.open(str(a)) as fa, wavmod.open(str(b)) as fb:
                 pa = np.frombuffer(fa.readframes(fa.getnframes()), dtype="<i2").astype(np.int32)
