@@ -301,6 +301,11 @@ int srn_gn_stats(const float* partials, float* mean, float* rstd, int B, int T, 
  * also gsum (B, groups, 2) = per-group sums of gamma * col (step between srn_gn_mish_bwd_partial and _apply). */
 int srn_chunk_colsum(const float* partial, const float* gamma, float* col, float* gsum, int B, int n_chunk, int C,
                      int groups, void* stream);
+/* out (B, N) = column sums of B row-major (R, N) matrices with row stride ld, batch stride R * ld (bias gradients
+ * dY^T 1 with B = 1; the gradient of a per-item broadcast add): two launches, partial (B, srn_colsum_chunks(R), N) is
+ * scratch.  Fixed summation order. */
+int srn_colsum(const float* x, float* partial, float* out, int B, int64_t R, int N, int ld, void* stream);
+int srn_colsum_chunks(int64_t R);
 /* softmax backward in place on dp: dp <- scale * p o (dp - rowsum(dp o p)); rows of L with stride ld. */
 int srn_softmax_bwd(const float* p, float* dp, int64_t rows, int L, int ld, float scale, void* stream);
 /* GEGLU (transformer.py:120-146): hg (rows, 2 inner) = [h | g]; a = h * gelu_erf(g); backward dhg from da. */

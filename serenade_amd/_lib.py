@@ -83,6 +83,8 @@ _SIGS = {
     "srn_gn_chunks": (c_int, [c_int]),
     "srn_gn_stats": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "srn_chunk_colsum": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "srn_colsum": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, _P]),
+    "srn_colsum_chunks": (c_int, [c_int64]),
     "srn_softmax_bwd": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P]),
     "srn_geglu_fwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "srn_geglu_bwd": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

@@ -300,30 +300,60 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-// ---- column sums of per-chunk partial sums: col[b][k][c] = sum_chunk partial[b][chunk][k][c], and (optional) the
-// per-group sums of gamma * col that the GroupNorm backward needs: gsum[b][g][k]
+// ---- column sums of per-chunk partial sums: col[b][i] = sum_chunk partial[b][chunk][i], i < n_out (= 2 C for the
+// (.., 2, C) buffers of the kernels above), one output per thread; and (optional) the per-group sums of gamma * col that
+// the GroupNorm backward needs, gsum[b][g][k], summed in a fixed order by the block that owns the group's channels
 __global__ __launch_bounds__(256) void chunk_colsum_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                                            float* __restrict__ col, float* __restrict__ gsum, int n_chunk,
-                                                           int C, int groups) {
-  __shared__ float cs[2 * MAXV * 256];  // gamma * column sums, for the per-group sums (fixed summation order)
-  const int b = blockIdx.x;
-  const float* p = partial + (int64_t)b * n_chunk * 2 * C;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int k = i / C, c = i - k * C;
-    float s = 0.f;
-    for (int ch = 0; ch < n_chunk; ++ch) s += p[((int64_t)ch * 2 + k) * C + c];
-    col[((int64_t)b * 2 + k) * C + c] = s;
-    if (gsum) cs[i] = s * gamma[c];
+                                                           int n_out, int C, int groups) {
+  __shared__ float cs[256];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* p = partial + (int64_t)b * n_chunk * n_out;
+  float s = 0.f;
+  if (i < n_out) {
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains keep the loads in flight
+    int ch = 0;
+    for (; ch + 4 <= n_chunk; ch += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] += p[(int64_t)(ch + u) * n_out + i];
+    }
+    for (; ch < n_chunk; ++ch) acc4[0] += p[(int64_t)ch * n_out + i];
+    s = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    col[(int64_t)b * n_out + i] = s;
   }
   if (gsum == nullptr) return;
+  // host guarantees C % 256 == 0 and 256 % (C / groups) == 0: a block's 256 outputs are whole groups of one k
+  const int k = (blockIdx.x * 256) / C, c0 = blockIdx.x * 256 - k * C;
+  cs[threadIdx.x] = i < n_out ? s * gamma[c0 + threadIdx.x] : 0.f;
   __syncthreads();
   const int cpg = C / groups;
-  if (threadIdx.x < 2 * groups) {
-    const int k = threadIdx.x / groups, g = threadIdx.x - k * groups;
-    float s = 0.f;
-    for (int c = 0; c < cpg; ++c) s += cs[k * C + g * cpg + c];
-    gsum[((int64_t)b * groups + g) * 2 + k] = s;
+  if (threadIdx.x < 256 / cpg) {
+    float t = 0.f;
+    for (int c = 0; c < cpg; ++c) t += cs[threadIdx.x * cpg + c];
+    gsum[((int64_t)b * groups + c0 / cpg + threadIdx.x) * 2 + k] = t;
   }
+}
+
+// ---- column sums of a row-major (R, N) matrix, stage 1: partial[chunk][n] = sum of COLSUM_ROWS rows (coalesced over n);
+// stage 2 is chunk_colsum_kernel.  The bias gradients and the broadcast-add gradients of the training step.
+constexpr int COLSUM_ROWS = 128;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                             int64_t R, int N, int ld) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
+  x += (int64_t)blockIdx.z * R * ld;                       // batch item
+  partial += (int64_t)blockIdx.z * gridDim.y * N;
+  if (n >= N) return;
+  const int64_t r1 = min(R, r0 + COLSUM_ROWS);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = r0;
+  for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += x[(r + u) * ld + n];
+  }
+  for (; r < r1; ++r) a[0] += x[r * ld + n];
+  partial[(int64_t)blockIdx.y * N + n] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 // ---- softmax backward in place: dp <- scale * p o (dp - sum_j dp_j p_j); one wave per row of L (row stride ld)
@@ -565,11 +595,27 @@ extern "C" int srn_gn_stats(const float* partials, float* mean, float* rstd, int
 extern "C" int srn_chunk_colsum(const float* partial, const float* gamma, float* col, float* gsum, int B, int n_chunk, int C,
                                 int groups, void* stream) {
   SRN_CHECK_ARG(partial && col && B > 0 && n_chunk > 0 && C > 0, "chunk_colsum: bad args");
-  SRN_CHECK_ARG(C <= 256 * MAXV, "chunk_colsum: C=%d unsupported", C);
-  SRN_CHECK_ARG(gsum == nullptr || (gamma != nullptr && groups > 0 && groups <= 128 && C % groups == 0),
-                "chunk_colsum: bad group arguments");
-  hipLaunchKernelGGL(chunk_colsum_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, partial, gamma, col, gsum,
-                     n_chunk, C, groups);
+  if (gsum != nullptr)
+    SRN_CHECK_ARG(gamma != nullptr && groups > 0 && C % groups == 0 && C % 256 == 0 && 256 % (C / groups) == 0,
+                  "chunk_colsum: C=%d groups=%d unsupported with gsum", C, groups);
+  const int n_out = 2 * C;
+  hipLaunchKernelGGL(chunk_colsum_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, partial, gamma, col, gsum, n_chunk, n_out, C, groups);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_colsum_chunks(int64_t R) { return (int)((R + COLSUM_ROWS - 1) / COLSUM_ROWS); }
+
+extern "C" int srn_colsum(const float* x, float* partial, float* out, int B, int64_t R, int N, int ld, void* stream) {
+  SRN_CHECK_ARG(x && partial && out && B > 0 && B < 65536 && R > 0 && N > 0 && ld >= N, "colsum: bad args");
+  const int chunks = srn_colsum_chunks(R);
+  SRN_CHECK_ARG(chunks < 65536, "colsum: too many rows");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)chunks, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, x, partial, R, N, ld);
+  SRN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(chunk_colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)partial, (const float*)nullptr, out, (float*)nullptr, chunks, N, N, 1);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -130,8 +130,7 @@ class _Conv(torch.autograd.Function):
                     mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
             dw = torch.stack(mats, dim=1).reshape(N, nt * C) if nt > 1 else mats[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            # column sums as a GEMV (rocBLAS), not a torch reduction: see AdamW._grad_norm
-            db = torch.mv(dy.reshape(-1, N).t(), torch.ones(B * T_out, device=dy.device, dtype=torch.float32))
+            db = _colsum(dy.reshape(-1, N))  # own kernel, not a torch reduction: see AdamW._grad_norm
         return dx, dw, db, None, None, None, None
 
 
@@ -155,8 +154,19 @@ def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None):
     return out
 
 
+def _colsum(x):
+    """column sums over the rows of a contiguous (R, N) matrix -> (N,), or per item of (B, R, N) -> (B, N)
+    (srn_colsum: two small launches, fixed summation order)"""
+    two_d = x.dim() == 2
+    B, R, N = (1, *x.shape) if two_d else x.shape
+    part = torch.empty(B, (R + 127) // 128, N, device=x.device, dtype=torch.float32)
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    _call("srn_colsum", x, part, out, B, R, N, N)
+    return out[0] if two_d else out
+
+
 class _AddRowBias(torch.autograd.Function):
-    """h (B, T, C) + b (B, C) broadcast over T.  Its backward's column sum is a batched GEMV (rocBLAS) instead of the
+    """h (B, T, C) + b (B, C) broadcast over T.  Its backward's column sums are srn_colsum launches instead of the
     reduction autograd would insert for the broadcast: see AdamW._grad_norm."""
 
     @staticmethod
@@ -166,8 +176,8 @@ class _AddRowBias(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, T, C = dy.shape
-        ones = torch.ones(B, 1, T, device=dy.device, dtype=dy.dtype)
-        return dy, torch.bmm(ones, dy).squeeze(1)
+        dy = dy.contiguous()
+        return dy, _colsum(dy)
 
 
 def pack_conv(w, c_pad=None):

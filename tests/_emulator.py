@@ -363,6 +363,9 @@ def emul_call(name, a):
         mv, rv = _v(mean, B * G).reshape(B, G), _v(rstd, B * G).reshape(B, G)
         for b in range(B):
             mv[b], rv[b] = _group_stats(part, b, T, C, G, eps)
+    elif name == "srn_colsum":
+        x, part, out, B, R, N, ld = a
+        _v(out, B * N).reshape(B, N)[:] = _v(x, B * R * ld).reshape(B, R, ld)[:, :, :N].sum(1)
     elif name == "srn_chunk_colsum":
         part, gamma, col, gsum, B, nch, C, G = a
         pv = _v(part, B * nch * 2 * C).reshape(B, nch, 2, C)
