@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void chunk_colsum_kernel(const float* __restri
 
 // ---- column sums of a row-major (R, N) matrix, stage 1: partial[chunk][n] = sum of COLSUM_ROWS rows (coalesced over n);
 // stage 2 is chunk_colsum_kernel.  The bias gradients and the broadcast-add gradients of the training step.
-constexpr int COLSUM_ROWS = 128;
+constexpr int COLSUM_ROWS = 32;  // small chunks: (N / 256) x (R / 32) workgroups keep the chip busy on an 8 MB matrix
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                              int64_t R, int N, int ld) {
   const int n = blockIdx.x * 256 + threadIdx.x;

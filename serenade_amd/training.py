@@ -159,7 +159,7 @@ def _colsum(x):
     (srn_colsum: two small launches, fixed summation order)"""
     two_d = x.dim() == 2
     B, R, N = (1, *x.shape) if two_d else x.shape
-    part = torch.empty(B, (R + 127) // 128, N, device=x.device, dtype=torch.float32)
+    part = torch.empty(B, (R + 31) // 32, N, device=x.device, dtype=torch.float32)  # srn_colsum_chunks(R)
     out = torch.empty(B, N, device=x.device, dtype=torch.float32)
     _call("srn_colsum", x, part, out, B, R, N, N)
     return out[0] if two_d else out

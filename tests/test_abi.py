@@ -70,3 +70,5 @@ def test_partial_sum_chunk_sizes_match_the_host_code():
     for T in (1, 31, 32, 33, 1000, 4352):
         assert h.srn_rowln_chunks(T) == (T + 31) // 32 == h.srn_gn_chunks(T)
     assert 1 <= h.srn_sumsq_blocks(10) <= h.srn_sumsq_blocks(84_287_728) <= 1024
+    for R in (1, 32, 33, 4096):
+        assert h.srn_colsum_chunks(R) == (R + 31) // 32
