@@ -322,6 +322,17 @@ int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64_t n, float
 /* clip_grad_norm_'s total norm: partial[i], i < srn_sumsq_blocks(n) (<= 1024), = fp64 sums of squares of slices of g;
  * the host adds them and takes the root. */
 int srn_sumsq(const float* g, int64_t n, double* partial, void* stream);
+/* Many small device-to-device copies in one launch (gradients of 262 parameter tensors into the flat gradient buffer):
+ * entry e copies len[e] floats from src[e] to dst + off[e].  The table is passed by value in the kernel arguments. */
+#define SRN_COPY_LIST_MAX 160
+typedef struct SrnCopyList {
+  int32_t n;
+  int32_t pad_;
+  const void* src[SRN_COPY_LIST_MAX];
+  int64_t off[SRN_COPY_LIST_MAX];
+  int64_t len[SRN_COPY_LIST_MAX];
+} SrnCopyList;
+int srn_multi_copy(const SrnCopyList* list, float* dst, void* stream);
 int srn_sumsq_blocks(int64_t n);
 
 #ifdef __cplusplus

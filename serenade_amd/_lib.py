@@ -48,6 +48,14 @@ class SrnResUnitParams(ctypes.Structure):
     ]
 
 
+SRN_COPY_LIST_MAX = 160
+
+
+class SrnCopyList(ctypes.Structure):
+    _fields_ = [("n", c_int32), ("pad_", c_int32), ("src", c_void_p * SRN_COPY_LIST_MAX),
+                ("off", c_int64 * SRN_COPY_LIST_MAX), ("len", c_int64 * SRN_COPY_LIST_MAX)]
+
+
 _P = c_void_p
 _SIGS = {
     "srn_abi_version": (c_int, []),
@@ -91,6 +99,7 @@ _SIGS = {
     "srn_adamw": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "srn_adamw_dyn": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
     "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "srn_multi_copy": (c_int, [POINTER(SrnCopyList), _P, _P]),
     "srn_sumsq_blocks": (c_int, [c_int64]),
 }
 

@@ -471,6 +471,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- many small device-to-device copies in one launch: entry e copies len[e] floats from src[e] to dst + off[e].
+// The table travels in the kernel arguments (no host-to-device copy, so a captured step can contain it).
+__global__ __launch_bounds__(256) void multi_copy_kernel(const SrnCopyList list, float* __restrict__ dst) {
+  const int e = blockIdx.x;
+  const int64_t n = list.len[e];
+  const float* __restrict__ src = reinterpret_cast<const float*>(list.src[e]);
+  float* __restrict__ d = dst + list.off[e];
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.y * 256)
+    reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(src)[i];
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) d[i] = src[i];
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 16384) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -616,6 +629,21 @@ extern "C" int srn_colsum(const float* x, float* partial, float* out, int B, int
   SRN_CHECK_LAUNCH();
   hipLaunchKernelGGL(chunk_colsum_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partial, (const float*)nullptr, out, (float*)nullptr, chunks, N, N, 1);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_multi_copy(const SrnCopyList* list, float* dst, void* stream) {
+  SRN_CHECK_ARG(list && dst && list->n > 0 && list->n <= SRN_COPY_LIST_MAX, "multi_copy: bad list");
+  int64_t longest = 0;
+  for (int e = 0; e < list->n; ++e) {
+    SRN_CHECK_ARG(list->src[e] != nullptr && list->len[e] >= 0 && list->off[e] >= 0, "multi_copy: bad entry %d", e);
+    longest = list->len[e] > longest ? list->len[e] : longest;
+  }
+  int64_t by = (longest / 4 + 255) / 256 / 4;  // ~4 float4 per thread on the longest entry
+  by = by < 1 ? 1 : (by > 256 ? 256 : by);
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)list->n, (unsigned)by), dim3(256), 0, (hipStream_t)stream, *list,
+                     dst);
   SRN_CHECK_LAUNCH();
   return 0;
 }

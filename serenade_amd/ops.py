@@ -156,6 +156,32 @@ class ResUnitOp:
         check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_hifigan_resunit")
 
 
+class MultiCopyOp:
+    """srn_multi_copy: many small device-to-device copies as one launch per 160 entries -- src tensor i (contiguous
+    fp32) goes to dst.view(-1)[offs[i] : offs[i] + src.numel()].  The table travels in the kernel arguments, so the call
+    can sit inside a captured hipGraph."""
+
+    __slots__ = ("srcs", "offs", "dst", "_lists", "_fn")
+
+    def __init__(self, srcs, offs, dst):
+        self.srcs, self.offs, self.dst = list(srcs), [int(o) for o in offs], dst
+        self._fn = _lib.lib().srn_multi_copy
+        self._lists = []
+        for i0 in range(0, len(self.srcs), _lib.SRN_COPY_LIST_MAX):
+            lst = _lib.SrnCopyList()
+            chunk = self.srcs[i0:i0 + _lib.SRN_COPY_LIST_MAX]
+            lst.n = len(chunk)
+            for j, t in enumerate(chunk):
+                assert t.is_contiguous() and t.dtype == torch.float32
+                lst.src[j], lst.off[j], lst.len[j] = t.data_ptr(), self.offs[i0 + j], t.numel()
+            self._lists.append(lst)
+
+    def __call__(self, stream=None):
+        st = stream if stream is not None else _stream()
+        for lst in self._lists:
+            check(self._fn(ctypes.byref(lst), _ptr(self.dst), st), "srn_multi_copy")
+
+
 _WPLANES = {}  # (data_ptr, version, shape, ...) -> (planes, weight) bf16 weight planes, split once per weight VALUE
 
 

@@ -408,13 +408,16 @@ class ParamStore:
 
     def backward_into_flat(self, loss):
         """`flat_grad` <- d loss / d parameters, OVERWRITING it (no zero_grad needed): torch.autograd.grad + one
-        multi-tensor copy, every op on the current stream.  Used by captured steps: the per-leaf AccumulateGrad nodes of
+        multi-tensor copy (srn_multi_copy), every op on the current stream.  Used by captured steps: the per-leaf AccumulateGrad nodes of
         `loss.backward()` run on the stream the leaf was created on, and the 262 in-place adds they issue from there
         raced with the capture stream's reuse of the gradient temporaries."""
-        ps = list(self.params.values())
+        names = list(self.params)
+        ps = [self.params[k] for k in names]
         grads = torch.autograd.grad(loss, ps, allow_unused=True)
         with torch.no_grad():
-            torch._foreach_copy_([p.grad for p, g in zip(ps, grads) if g is not None], [g for g in grads if g is not None])
+            have = [(g.contiguous(), self.spans[k][0]) for k, g in zip(names, grads) if g is not None]
+            # one launch per 160 tensors (torch._foreach_copy_ issues one memcpy per tensor on this stack: 245 launches)
+            ops.MultiCopyOp([g for g, _ in have], [o for _, o in have], self.flat_grad)()
             for p, g in zip(ps, grads):
                 if g is None:
                     p.grad.zero_()

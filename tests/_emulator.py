@@ -432,6 +432,12 @@ def emul_resunit(kw):
     _v(g("out"), B * T * C).reshape(B, T, C)[:] = y
 
 
+def emul_multi_copy(self_, stream=None):
+    flat = self_.dst.view(-1)
+    for t, o in zip(self_.srcs, self_.offs):
+        flat[o:o + t.numel()] = t.reshape(-1)
+
+
 class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
@@ -440,6 +446,8 @@ class installed:
         self._mods = (models, vocoder, sifigan, features, training)
         self._saved = (ops.ConvOp.__call__, ops.CallOp.__call__, [m._require_cuda for m in self._mods],
                        ops.ResUnitOp.__call__)
+        self._saved_mc = ops.MultiCopyOp.__call__
+        ops.MultiCopyOp.__call__ = emul_multi_copy
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)
         ops.ResUnitOp.__call__ = lambda self_, stream=None: emul_resunit(self_.kw)
         ops.CallOp.__call__ = lambda self_, stream=None: emul_call(self_.name, self_.targs)
@@ -449,5 +457,6 @@ class installed:
 
     def __exit__(self, *exc):
         ops.ConvOp.__call__, ops.CallOp.__call__, guards, ops.ResUnitOp.__call__ = self._saved
+        ops.MultiCopyOp.__call__ = self._saved_mc
         for m, g in zip(self._mods, guards):
             m._require_cuda = g

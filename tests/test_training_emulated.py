@@ -212,3 +212,19 @@ def test_checkpoint_resume_and_lr_schedule(tmp_path):
     assert torch.equal(a.flat, b.flat) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v) and ob.lr == 5e-4
     ck = torch.load(str(tmp_path / "ck" / "checkpoint-2steps.pkl"))
     assert set(ck) == {"model", "optimizer", "scheduler", "steps", "epochs"}
+
+
+def test_overwrite_gradient_path_equals_accumulation():
+    """ParamStore.backward_into_flat (autograd.grad + srn_multi_copy) == zero_grad + loss.backward(); a parameter the
+    loss does not touch ends up zero, not stale"""
+    g = torch.Generator().manual_seed(1)
+    sd = {f"p{i}": torch.randn(s, generator=g) for i, s in enumerate([(7, 5), (33,), (64, 9), (3,)])}
+    with _emulator.installed():
+        a, b = training.ParamStore(sd, torch.device("cpu")), training.ParamStore(sd, torch.device("cpu"))
+        loss = lambda st: sum((st.params[k] ** 2).sum() * (i + 1) for i, k in enumerate(sd) if k != "p1")
+        for p in a.params.values():
+            p.grad.fill_(7.0)  # stale values in every gradient
+        a.backward_into_flat(loss(a))
+        b.zero_grad()
+        loss(b).backward()
+    assert torch.equal(a.flat_grad, b.flat_grad) and not a.params["p1"].grad.any()
