@@ -114,3 +114,37 @@ def test_front_end_on_the_gpu():
     _check(dev, 2000, 1)
     with pytest.raises(RuntimeError):
         features.logmelfilterbank(torch.zeros(1000), SR, fft_size=FFT, hop_size=HOP)  # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_front_end_at_utterance_scale_against_the_restatement(capsys):
+    """8 utterances of 1024 frames (10.24 s): values against the numpy restatement on one utterance, and the
+    restatement's host time beside the GPU's (printed: the f3 side-by-side, tools/featbench.py times the GPU alone)"""
+    import time
+    assert torch.cuda.is_available()
+    B, T = 8, 1024
+    n = T * HOP
+    audio = (np.random.default_rng(0).standard_normal((B, n)) * 0.1).astype(np.float32)
+    a = torch.from_numpy(audio).cuda()
+    kw = dict(fft_size=FFT, hop_size=HOP, win_length=480, num_mels=80, fmin=63, fmax=12000)
+    report = {}
+    for name, gpu_fn, cpu_fn, tol in (
+            ("logmel", lambda: features.logmelfilterbank(a, SR, **kw), lambda: FO.logmelfilterbank(audio[0], SR, **kw), 5e-5),
+            ("loudness", lambda: features.loudness_extract(a, SR, HOP), lambda: FO.loudness_extract(audio[0], SR, HOP), 5e-6)):
+        for _ in range(3):
+            r = gpu_fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            r = gpu_fn()
+        torch.cuda.synchronize()
+        gpu = (time.perf_counter() - t0) / 10
+        t1 = time.perf_counter()
+        ref = cpu_fn()
+        cpu = time.perf_counter() - t1
+        err = float(np.abs(r[0].cpu().numpy()[: len(ref)] - ref).max())
+        assert err < tol, (name, err)
+        report[name] = {"gpu_frames_per_s": B * r.shape[1] / gpu, "cpu_numpy_frames_per_s": len(ref) / cpu, "max_abs_err": err}
+        assert report[name]["gpu_frames_per_s"] > 10 * report[name]["cpu_numpy_frames_per_s"]
+    with capsys.disabled():
+        print("\nfront-end side-by-side:", report)

@@ -52,15 +52,6 @@ def main():
     voc.model._invalidate()
     wb = voc.decode_batch(m0)
     print("vocoder-only bf16x3 vs fp32 on the same mel: wave abs err", (wb - w0).abs().max().item())
-    if "--oracle" in sys.argv:
-        from oracle import serenade_oracle as O
-        i = 3
-        one = {k: v[i:i + 1] for k, v in d.items()}
-        ref = O.serenade_inference(sd, one["x"], one["lengths"], one["midi"], one["lft"], one["ref_x"],
-                                   one["ref_lengths"], one["ref_logmel"], one["ref_midi"], one["ref_lft"], one["z"])
-        for name in res:
-            e = ((res[name][0][i].cpu() - ref).abs().max() / ref.abs().max()).item()
-            print(f"{name} vs oracle: mel rel err {e:.3e}")
 
 
 if __name__ == "__main__":
