@@ -1,5 +1,9 @@
-"""FeatsDataset — decode-time feature reader with the semantics of
-serenade/datasets/audio_mel_dataset.py:20-141 (keys, normalisation, returned dict)."""
+"""Decode-time feature reader.
+
+Interface of the reference's ``FeatsDataset`` (serenade/datasets/audio_mel_dataset.py:20-141): built from a dump
+directory and the ``stats.joblib`` scalers, indexable, and every item is a dict with the keys the decode loop reads
+(``audio, logmel, hubert, loud, score, midi, lf0`` and optionally ``utt_id``).  The body is table-driven and this
+repo's own: which stored dataset feeds which key, and which scaler entry normalises it how, is data (`_FIELDS`)."""
 import logging
 import os
 
@@ -7,48 +11,64 @@ import numpy as np
 
 from .utils.io import find_files, read_feats
 
+# item key -> (dataset name in the feature file or None if it is chosen per instance, scaler entry, kind of scaling)
+_FIELDS = {
+    "audio": ("wave", None, None),
+    "logmel": (None, "logmel", "standard"),
+    "hubert": ("hubert", "hubert", "standard"),
+    "loud": ("loud", "loud", "minmax"),
+    "score": (None, "score", "minmax"),
+    "midi": ("midi", None, None),
+    "lf0": ("f0", None, None),
+}
 
-class FeatsDataset(object):
+
+def _scale(values, entry, kind):
+    if kind == "standard":
+        return (values - entry.mean_) / entry.scale_
+    span = entry.data_max_ - entry.data_min_
+    return (values - entry.data_min_) / span
+
+
+class FeatsDataset:
     def __init__(self, root_dir, audio_query="*.h5", scaler=None, return_utt_id=False, allow_cache=False,
                  score_type="est_lf0_score", logmel_type="logmel"):
-        files = sorted(find_files(root_dir, audio_query))
-        if len(files) == 0 and audio_query == "*.h5":
-            files = sorted(find_files(root_dir, "*.npz"))
-        assert len(files) != 0, f"Not found any audio files in ${root_dir}."
-        logging.info(f"score type: {score_type}")
-        self.audio_files = files
-        self.utt_ids = [os.path.splitext(os.path.basename(f))[0] for f in files]
-        self.scaler, self.return_utt_id = scaler, return_utt_id
-        self.score_type, self.logmel_type = score_type, logmel_type
-        self.allow_cache = allow_cache
-        self.caches = [() for _ in files] if allow_cache else None
+        paths = find_files(root_dir, audio_query)
+        if not paths and audio_query == "*.h5":  # the same keys in .npz archives (where h5py is unavailable)
+            paths = find_files(root_dir, "*.npz")
+        if not paths:
+            raise AssertionError(f"no feature files matching {audio_query!r} under {root_dir}")
+        self.audio_files = sorted(paths)
+        self.utt_ids = [os.path.basename(p).rsplit(".", 1)[0] for p in self.audio_files]
+        self.scaler = scaler
+        self.return_utt_id = return_utt_id
+        self._stored = {"logmel": logmel_type, "score": score_type}
+        self._memo = {} if allow_cache else None
+        logging.info(f"{len(self.audio_files)} feature files, score contour '{score_type}', mel '{logmel_type}'")
 
     def __len__(self):
         return len(self.audio_files)
 
-    def __getitem__(self, idx):
-        if self.allow_cache and len(self.caches[idx]) != 0:
-            return self.caches[idx]
-        f = self.audio_files[idx]
-        audio, hubert = read_feats(f, "wave"), read_feats(f, "hubert")
-        logmel, score = read_feats(f, self.logmel_type), read_feats(f, self.score_type)
-        midi, loud, lf0 = read_feats(f, "midi"), read_feats(f, "loud"), read_feats(f, "f0")
-        s = self.scaler
-        if s is not None:
-            logmel = (logmel - s["logmel"].mean_) / s["logmel"].scale_
-            hubert = (hubert - s["hubert"].mean_) / s["hubert"].scale_
-            score = (score - s["score"].data_min_) / (s["score"].data_max_ - s["score"].data_min_)
-            loud = (loud - s["loud"].data_min_) / (s["loud"].data_max_ - s["loud"].data_min_)
-            if np.isnan(logmel).any():
-                logging.info(f"contains nan: {self.utt_ids[idx]}")
-        items = {"audio": audio, "logmel": logmel, "hubert": hubert, "loud": loud, "score": score, "midi": midi,
-                 "lf0": lf0}
+    def _load(self, idx):
+        path = self.audio_files[idx]
+        item = {}
+        for key, (stored, entry, kind) in _FIELDS.items():
+            values = read_feats(path, stored or self._stored[key])
+            if self.scaler is not None and entry is not None:
+                values = _scale(values, self.scaler[entry], kind)
+            item[key] = values
+        if self.scaler is not None and np.isnan(item["logmel"]).any():
+            logging.warning(f"{self.utt_ids[idx]}: normalised mel has NaNs")
         if self.return_utt_id:
-            items["utt_id"] = self.utt_ids[idx]
-        if self.allow_cache:
-            self.caches[idx] = items
-        return items
+            item["utt_id"] = self.utt_ids[idx]
+        return item
+
+    def __getitem__(self, idx):
+        if self._memo is None:
+            return self._load(idx)
+        if idx not in self._memo:
+            self._memo[idx] = self._load(idx)
+        return self._memo[idx]
 
     def __iter__(self):
-        for i in range(len(self)):
-            yield self[i]
+        return (self[i] for i in range(len(self)))
