@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SRN_ABI_VERSION 2
+#define SRN_ABI_VERSION 3
 #define SRN_MAX_TAPS 16
 
 /* prologue activation applied to the gathered input elements */
@@ -334,6 +334,70 @@ typedef struct SrnCopyList {
 } SrnCopyList;
 int srn_multi_copy(const SrnCopyList* list, float* dst, void* stream);
 int srn_sumsq_blocks(int64_t n);
+
+/*
+ * Analysis front-end between HiFi-GAN and SiFiGAN -- SURVEY 8 row f1, serenade/bin/ssc_postprocessing.py:142-222.
+ * The reference calls pyworld (`pw.cheaptrick` :167, `pw.d4c` :168, `pw.code_aperiodicity` :171), pysptk
+ * (`pysptk.sp2mc` :169) and sifigan.utils.features (`dilated_factor` :201-210, `SignalGenerator` :105-111,219-222):
+ * third-party code absent from the reference tree, restated from the published algorithms in oracle/world_oracle.py
+ * (parity unpinned).  `convert_continuos_f0` (:51-72) and the np.interp length match (:159-166) are in-tree and pinned.
+ * All analysis arithmetic is float64 (WORLD's precision); one workgroup per 5 ms frame, everything in LDS.
+ */
+typedef struct SrnWorldParams {
+  int32_t n_batch, max_frames;  /* grid = max_frames x n_batch; frames >= n_frames[b] are skipped */
+  int32_t fs, fft_size;         /* cheaptrick: 512 / 1024 / 2048 (GetFFTSizeForCheapTrick); d4c: 1024 / 2048 */
+  const double* x; int64_t x_bs; const int32_t* x_len; /* (B, x_bs) float64 waveforms and their valid lengths */
+  const double* f0; const double* t; int64_t f_bs;     /* (B, f_bs) F0 in Hz and temporal positions in seconds */
+  const int32_t* n_frames;      /* (B,) */
+  const double* twiddle;        /* fft_size/2 pairs (cos, -sin)(2 pi k / fft_size) */
+  double q1, f0_floor;          /* cheaptrick: compensation-lifter q1 (-0.15); F0 <= f0_floor is analysed as 500 Hz */
+  double threshold;             /* d4c: Love-Train voicing threshold (0.85) */
+  double unvoiced_db;           /* d4c: what unvoiced / rejected frames hold, 20 log10(1 - 1e-12) */
+  const double* band_window; int32_t band_window_len; /* d4c: Nuttall window over the group delay of one band */
+  int32_t n_bands;              /* d4c: 3 kHz bands below min(15 kHz, fs/2 - 3 kHz): 3 at 24 kHz */
+  double* out0; int64_t out0_bs; int32_t ld_out0; /* cheaptrick: spectral envelope (fft_size/2+1 per frame) or NULL;
+                                                    * d4c: band aperiodicity in dB (n_bands per frame) */
+  double* out1; int64_t out1_bs; int32_t ld_out1; /* cheaptrick: liftered cepstrum X (its c2r is log sp) or NULL */
+} SrnWorldParams;
+/* pw.cheaptrick: F0-adaptive Hanning window of 3 periods, power spectrum, DC correction, smoothing over 2 F0 / 3,
+ * cepstral smoothing + q1 compensation lifter. */
+int srn_world_cheaptrick(const SrnWorldParams* p, void* stream);
+/* pw.d4c followed by pw.code_aperiodicity: Love-Train voicing check, static group delay, band aperiodicity in dB. */
+int srn_world_d4c(const SrnWorldParams* p, void* stream);
+/* out (rows, n_out) = g(in (rows, K)) @ mat_t (K, n_out), g = log (take_log) or identity, float64: pysptk.sp2mc as one
+ * matrix (log -> irfft -> c0 / 2 -> SPTK freqt is linear in log sp), n_out <= 64. */
+int srn_world_project(const double* in, int64_t rows, int K, int ld_in, const double* mat_t, int n_out, int take_log,
+                      double* out, int ld_out, void* stream);
+/* c (rows, ld_out) float32 = ([a | b] - mean) / scale (StandardScaler.transform :185-199, torch.FloatTensor :213);
+ * mean = scale = NULL: plain concatenation. */
+int srn_world_pack_features(const double* a, int na, const double* b, int nb, const double* mean, const double* scale,
+                            float* out, int64_t rows, int ld_out, void* stream);
+/* float32 waveform -> float64 samples; pcm16: through the PCM_16 file hop of the reference (decode writes
+ * lrint(x * 32767), ssc_decode.py:449-455; post-processing reads int16 / 32768, ssc_postprocessing.py:143). */
+int srn_wave_to_f64(const float* wave, double* out, int64_t n, int pcm16, void* stream);
+/* np.maximum(np.interp(np.linspace(0, n_in - 1, n_out), arange(n_in), f0), 0); copy when n_in == n_out (:159-166). */
+int srn_f0_match_length(const double* in, int64_t in_bs, const int32_t* n_in, double* out, int64_t out_bs,
+                        const int32_t* n_out, int n_batch, int max_out, void* stream);
+/* convert_continuos_f0 (:51-72): cf0 float64, uv float32 (both (B, bs)), ok[b] = 0 when an item has no voiced frame. */
+int srn_cont_f0(const double* f0, int64_t bs, const int32_t* n_frames, double* cf0, float* uv, int32_t* ok,
+                int n_batch, void* stream);
+/* SignalGenerator(signal_types=["sine"]) and the dilated-factor tracks np.repeat(dilated_factor(f0, fs, dense), us). */
+typedef struct SrnExcitationParams {
+  int32_t n_batch, max_frames, fs, hop;
+  const double* f0;        /* (B, f_bs) contour driving the sine (cf0 or f0, `sine_f0_type`) */
+  const double* df_f0;     /* (B, f_bs) contour driving the dilated factors (`df_f0_type`) */
+  int64_t f_bs;
+  const int32_t* n_frames;
+  double* phase_ws;        /* (B, f_bs) scratch: phase at every frame start */
+  const float* noise;      /* (B, max_frames * hop) standard-normal draws standing in for torch.randn, or NULL */
+  float* sine;             /* (B, max_frames * hop) */
+  float sine_amp, noise_amp;
+  int32_t n_df;            /* <= 4 */
+  float* dfs[4];           /* track i: (B, max_frames * df_upsample[i]) */
+  int32_t df_upsample[4];  /* np.cumprod(upsample_scales) */
+  double dense_factors[4];
+} SrnExcitationParams;
+int srn_sifigan_excitation(const SrnExcitationParams* p, void* stream);
 
 #ifdef __cplusplus
 }

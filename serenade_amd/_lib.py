@@ -5,7 +5,7 @@ oracle under ``oracle/`` is never imported from here.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SERENADE_AMD_LIB") or os.path.join(_HERE, "libserenade_hip.so")  # env: developer builds
@@ -56,6 +56,27 @@ class SrnCopyList(ctypes.Structure):
                 ("off", c_int64 * SRN_COPY_LIST_MAX), ("len", c_int64 * SRN_COPY_LIST_MAX)]
 
 
+class SrnWorldParams(ctypes.Structure):
+    _fields_ = [
+        ("n_batch", c_int32), ("max_frames", c_int32), ("fs", c_int32), ("fft_size", c_int32),
+        ("x", c_void_p), ("x_bs", c_int64), ("x_len", c_void_p),
+        ("f0", c_void_p), ("t", c_void_p), ("f_bs", c_int64), ("n_frames", c_void_p), ("twiddle", c_void_p),
+        ("q1", c_double), ("f0_floor", c_double), ("threshold", c_double), ("unvoiced_db", c_double),
+        ("band_window", c_void_p), ("band_window_len", c_int32), ("n_bands", c_int32),
+        ("out0", c_void_p), ("out0_bs", c_int64), ("ld_out0", c_int32),
+        ("out1", c_void_p), ("out1_bs", c_int64), ("ld_out1", c_int32),
+    ]
+
+
+class SrnExcitationParams(ctypes.Structure):
+    _fields_ = [
+        ("n_batch", c_int32), ("max_frames", c_int32), ("fs", c_int32), ("hop", c_int32),
+        ("f0", c_void_p), ("df_f0", c_void_p), ("f_bs", c_int64), ("n_frames", c_void_p), ("phase_ws", c_void_p),
+        ("noise", c_void_p), ("sine", c_void_p), ("sine_amp", c_float), ("noise_amp", c_float), ("n_df", c_int32),
+        ("dfs", c_void_p * 4), ("df_upsample", c_int32 * 4), ("dense_factors", c_double * 4),
+    ]
+
+
 _P = c_void_p
 _SIGS = {
     "srn_abi_version": (c_int, []),
@@ -101,6 +122,14 @@ _SIGS = {
     "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "srn_multi_copy": (c_int, [POINTER(SrnCopyList), _P, _P]),
     "srn_sumsq_blocks": (c_int, [c_int64]),
+    "srn_world_cheaptrick": (c_int, [POINTER(SrnWorldParams), _P]),
+    "srn_world_d4c": (c_int, [POINTER(SrnWorldParams), _P]),
+    "srn_world_project": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, _P, c_int, _P]),
+    "srn_world_pack_features": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int64, c_int, _P]),
+    "srn_wave_to_f64": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "srn_f0_match_length": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, c_int, _P]),
+    "srn_cont_f0": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P]),
+    "srn_sifigan_excitation": (c_int, [POINTER(SrnExcitationParams), _P]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -121,7 +150,7 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
-        if h.srn_abi_version() != 2:
+        if h.srn_abi_version() != 3:
             raise RuntimeError("libserenade_hip.so ABI version mismatch")
         _lib = h
     return _lib

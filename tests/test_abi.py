@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_error_reporting_without_gpu(lib):
-    assert lib.srn_abi_version() == 2
+    assert lib.srn_abi_version() == 3
     assert lib.srn_conv_gemm(None, None) == -1
     assert b"null params" in lib.srn_last_error()
     p = _lib.SrnConvParams()
@@ -43,7 +43,7 @@ def test_error_reporting_without_gpu(lib):
     assert b"null in0" in lib.srn_last_error()
 
 
-@pytest.mark.parametrize("name", ["SrnConvParams", "SrnResUnitParams", "SrnCopyList"])
+@pytest.mark.parametrize("name", ["SrnConvParams", "SrnResUnitParams", "SrnCopyList", "SrnWorldParams", "SrnExcitationParams"])
 def test_struct_layout_matches_c(tmp_path, name):
     cls = getattr(_lib, name)
     fields = [f[0] for f in cls._fields_]

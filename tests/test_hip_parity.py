@@ -129,7 +129,7 @@ ALL_TILES = (0, 1, 2, 3, 4, 5)
 
 def test_library_exports_and_error_path(dev):
     lib = _lib.lib()
-    assert lib.srn_abi_version() == 2
+    assert lib.srn_abi_version() == 3
     rc = lib.srn_conv_gemm(None, None)
     assert rc != 0 and b"null" in lib.srn_last_error()
 
