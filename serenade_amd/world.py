@@ -257,8 +257,9 @@ def match_length(f0_list, n_out, device):
         buf[i, :n_in[i]] = np.asarray(f, dtype=np.float64).ravel()
     src = torch.from_numpy(buf).to(device)
     out = torch.zeros(B, max(n_out), dtype=_F64, device=device)
-    check(_lib.lib().srn_f0_match_length(src.data_ptr(), src.stride(0), _i32(n_in, device).data_ptr(), out.data_ptr(),
-                                         out.stride(0), _i32(n_out, device).data_ptr(), B, max(n_out), _stream()),
+    n_in_d, n_out_d = _i32(n_in, device), _i32(n_out, device)  # named: the pointers must outlive the launch call
+    check(_lib.lib().srn_f0_match_length(src.data_ptr(), src.stride(0), n_in_d.data_ptr(), out.data_ptr(),
+                                         out.stride(0), n_out_d.data_ptr(), B, max(n_out), _stream()),
           "srn_f0_match_length")
     return out
 

@@ -205,16 +205,20 @@ def test_gpu_cheaptrick_and_sp2mc_vs_oracle():
     sp = world.cheaptrick(_cuda(x), _cuda(f0), _cuda(t), FS)
     assert sp.shape == sp_ref.shape and sp.dtype == torch.float64
     err = np.abs(np.log(sp.cpu().numpy() / sp_ref)).max()
-    assert err < 1e-9, err                       # float64 both sides: FFT / summation order only
+    # float64 on both sides, yet not 1e-12: WORLD's LinearSmoothing differences a running integral of the power
+    # spectrum, so a band 90 dB below the total carries eps * 1e9 -- the oracle itself moves by 1.1e-7 (log) on this
+    # signal when its cumsum runs in extended precision.  Summation order is all that differs here.
+    assert err < 1e-6, err
     mc_ref = W.sp2mc(sp_ref, 39, 0.466)
     mc = world.sp2mc(sp, 39, 0.466).cpu().numpy()
-    assert np.abs(mc - mc_ref).max() < 1e-9
+    assert np.abs(mc - mc_ref).max() < 1e-6
+    assert np.abs(world.sp2mc(_cuda(sp_ref), 39, 0.466).cpu().numpy() - mc_ref).max() < 1e-11   # the projection alone
     # batched, other transform sizes
     for fft_size in (512, 2048):
         f0b = np.maximum(f0, 0) if fft_size != 512 else np.where(f0 > 0, np.maximum(f0, 160.0), 0.0)
         ref = W.cheaptrick(x, f0b, t, FS, fft_size=fft_size)
         got = world.cheaptrick(_cuda(np.stack([x, x])), _cuda(np.stack([f0b, f0b])), _cuda(t), FS, fft_size=fft_size)
-        assert np.abs(np.log(got[1].cpu().numpy() / ref)).max() < 1e-9
+        assert np.abs(np.log(got[1].cpu().numpy() / ref)).max() < 1e-6
         assert torch.equal(got[0], got[1])
 
 
@@ -263,9 +267,12 @@ def test_gpu_analyzer_vs_oracle_ragged_batch():
         ref = W.analyze(W.pcm16_roundtrip(waves[i]), lf0[i], FS, mean=mean, scale=scale)
         assert ref["ok"] and bool(feats["ok"][i].item())
         got_c = c[i, :, :F[i]].T.cpu().numpy()
-        voiced = ref["bap"][:, 0] != ref["bap"].max()
-        flips = (got_c[:, 40] != got_c[:, 40].max()) != voiced
+        unv = 20 * np.log10(1 - 1e-12)
+        got_bap = feats["bap"][i, :F[i]].cpu().numpy()
+        flips = (got_bap == unv).all(1) != (ref["bap"] == unv).all(1)   # Love-Train threshold decisions
         assert flips.mean() < 0.005
+        assert np.abs(got_bap[~flips] - ref["bap"][~flips]).max() < 1e-6
+        assert np.abs(feats["mcep"][i, :F[i]].cpu().numpy() - ref["mcep"]).max() < 1e-6
         assert np.abs(got_c[:, :40] - ref["c"][:, :40]).max() < 1e-5                       # float32 output
         assert np.abs(got_c[~flips, 40:] - ref["c"][~flips, 40:]).max() < 1e-4
         assert np.array_equal(feats["cf0"][i, :F[i]].cpu().numpy(), ref["cf0"])              # pinned arithmetic
