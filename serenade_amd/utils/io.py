@@ -109,3 +109,20 @@ def write_wav_pcm16(path, wave, sr):
         f.setsampwidth(2)
         f.setframerate(int(sr))
         f.writeframes(x.tobytes())
+
+
+def read_wav(path):
+    """`soundfile.read(path)` for the files this pipeline writes: (float64 samples in [-1, 1), sampling rate).
+    PCM_16 is normalised by 32768 as libsndfile does (ssc_postprocessing.py:143)."""
+    try:
+        import soundfile as sf
+        return sf.read(path)
+    except ImportError:
+        pass
+    import wave as _wave
+    with _wave.open(path, "rb") as f:
+        if f.getsampwidth() != 2:
+            raise RuntimeError(f"{path}: only PCM_16 wav files are readable without the soundfile package")
+        sr, ch = f.getframerate(), f.getnchannels()
+        x = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2").astype(np.float64) / 32768.0
+    return (x.reshape(-1, ch) if ch > 1 else x), sr

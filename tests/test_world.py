@@ -294,3 +294,73 @@ def test_gpu_all_unvoiced_item_is_flagged():
     assert int(feats["ok"][0]) == 0 and torch.isfinite(c).all()
     with pytest.raises(ValueError):
         an(_cuda(x[None], torch.float32), [4800], [np.full(21, 7000.0)])
+
+
+# ------------------------------------------------------------------------------------------------ stage-9 CLI
+def test_postprocessing_cli_overrides():
+    from serenade_amd.bin import ssc_postprocessing as PP
+    cfg = PP.parse_overrides(["generator=sifigan", "in_dir=/tmp/x", "stats=s.joblib", "checkpoint_path=m.pkl",
+                              "noise_amp=0", "dense_factors=[1,2,4,8]", "generator.channels=64"])
+    assert cfg["in_dir"] == "/tmp/x" and cfg["noise_amp"] == 0 and cfg["dense_factors"] == [1, 2, 4, 8]
+    assert cfg["generator"]["channels"] == 64 and cfg["generator"]["upsample_scales"] == [5, 4, 3, 2]
+    assert cfg["sample_rate"] == 24000 and cfg["frame_period"] == 5 and cfg["mcep_dim"] == 39 and cfg["seed"] == 100
+    for bad in (["generator=hifigan"], ["nonsense=1"], ["in_dir"], ["generator.nope.x=1"]):
+        with pytest.raises(SystemExit):
+            PP.parse_overrides(bad)
+
+
+@pytest.mark.gpu
+def test_gpu_postprocessing_cli_end_to_end(tmp_path):
+    """decode-CLI outputs (wav + lf0) -> f1 -> SiFiGAN generator on the card, against the CPU restatements chained
+    the same way (noise_amp = 0: the reference's noise is a torch.randn draw on the device)."""
+    from joblib import dump
+    from sklearn.preprocessing import StandardScaler
+    from oracle import sifigan_oracle as SO
+    from serenade_amd import _shapes, sifigan
+    from serenade_amd.bin import ssc_postprocessing as PP
+    from serenade_amd.utils.io import read_wav, write_wav_pcm16
+    from serenade_amd.utils.synth import fill_state_dict
+    from tests._weights import fold_weight_norm
+    rng = np.random.default_rng(11)
+    d = tmp_path / "results" / "test"
+    d.mkdir(parents=True)
+    items = {"Alto_song_0001_Breathy": song(0.6, 7), "Tenor_song_0002_Vibrato": song(0.45, 8)}
+    for name, (x, f0) in items.items():
+        write_wav_pcm16(str(d / f"{name}.wav"), 0.9 * x / np.abs(x).max(), FS)
+        np.savez(d / f"{name}.npz", lf0=f0[::2].astype(np.float32))       # 10 ms contour, as ssc_decode writes it
+    write_wav_pcm16(str(d / "Alto_song_0001_gt.wav"), items["Alto_song_0001_Breathy"][0] * 0.1, FS)
+    write_wav_pcm16(str(d / "00_Breathy_reference.wav"), items["Alto_song_0001_Breathy"][0] * 0.1, FS)
+    write_wav_pcm16(str(d / "no_contour.wav"), items["Alto_song_0001_Breathy"][0] * 0.1, FS)
+    scaler = {"mcep": StandardScaler().fit(rng.standard_normal((60, 40)) * 2 - 1),
+              "bap": StandardScaler().fit(rng.standard_normal((60, 3)) * 10 - 20)}
+    dump(scaler, tmp_path / "stats.joblib")
+    cfg = sifigan.DEFAULT_PARAMS
+    sd = fill_state_dict(_shapes.as_meta(sifigan.sifigan_shapes(**cfg)), seed=5)
+    torch.save({"model": {"generator": sd}}, tmp_path / "model.pkl")
+    import serenade_amd
+    serenade_amd.set_precision("fp32")
+    try:
+        frames = PP.main(["generator=sifigan", f"in_dir={tmp_path / 'results'}", f"stats={tmp_path / 'stats.joblib'}",
+                          f"checkpoint_path={tmp_path / 'model.pkl'}", "noise_amp=0"])
+    finally:
+        serenade_amd.set_precision("bf16x3")
+    names = sorted(p.name for p in d.iterdir() if p.name.endswith("_sifigan.wav"))
+    assert names == [f"{n}_sifigan.wav" for n in sorted(items)]
+    w = fold_weight_norm(sd)
+    mean = np.concatenate([scaler["mcep"].mean_, scaler["bap"].mean_])
+    scale = np.concatenate([scaler["mcep"].scale_, scaler["bap"].scale_])
+    total = 0
+    for name in items:
+        x, sr = read_wav(str(d / f"{name}.wav"))
+        ref = W.analyze(x, np.load(d / f"{name}.npz")["lf0"], FS, mean=mean, scale=scale)
+        total += len(ref["f0"])
+        cf0_32 = torch.tensor(ref["cf0"], dtype=torch.float32).view(1, 1, -1)
+        sine = W.signal_generator_sine(cf0_32, FS, 120, 0.1, 0.0)
+        c = torch.tensor(ref["c"], dtype=torch.float32).T.unsqueeze(0)
+        dfs = [torch.tensor(v, dtype=torch.float32).view(1, 1, -1) for v in ref["dfs"]]
+        y_ref, _ = SO.sifigan_forward(w, sine, c, dfs, cfg)
+        y, sr2 = read_wav(str(d / f"{name}_sifigan.wav"))
+        assert sr2 == FS and len(y) == y_ref.numel() == len(ref["f0"]) * 120
+        q = np.clip(np.rint(y_ref.view(-1).numpy().astype(np.float64) * 32767.0), -32768, 32767) / 32768.0
+        assert np.abs(y - q).max() <= 2.0 / 32768.0      # PCM_16 LSBs: fp32 generator on both sides
+    assert frames == total
