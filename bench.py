@@ -108,6 +108,8 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
     return {"workload": f"whole-model training step (encoder + GST + estimator, cfm + prior loss), B={B} x L={L} "
                         f"(ragged lengths), exact fp32, dropout 0.05, clip 1.0, AdamW lr 8e-4",
             "ms_per_step": dt * 1e3, "frames_per_s": B * L / dt, "tflops": fl / dt / 1e12,
+            "dropout_timed_at": 0.05,
+            "dropout_validated_at": 0.0,  # the reference's mask draws cannot be reproduced: gradient parity runs use p = 0
             "parameters": int(sum(v.numel() for v in model.params.values())), **phases,
             "loss_first": loss0, "loss_last": float(loss), "captured_as_hipgraph": graphed,
             "peak_hbm_gib": (torch.cuda.max_memory_allocated(dev) - base) / 2**30}
@@ -115,12 +117,8 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
 
 def build_id():
     """hash of the kernel sources + C ABI the loaded library was built from (profiles/ records carry the same id)"""
-    h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "serenade_amd", "csrc", "*")) +
-                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
-    return h.hexdigest()[:12]
+    from serenade_amd import build
+    return build.source_id()
 
 
 def build_models(dev):
@@ -240,7 +238,9 @@ def cpu_train_baseline(sd, B=1, L=256):
         torch.set_num_threads(saved)
     med = statistics.median(ts)
     return {"value": B * L / med, "unit": "frames/s", "cores": threads, "kind": "port", "median_s": med,
-            "sample": f"B={B} x L={L} forward + backward through the oracle (torch autograd, fp32), median of 3"}
+            "sample": f"B={B} x L={L} forward + backward through the oracle (torch autograd, fp32), median of 3",
+            "workload_differs_from_gpu_line": f"CPU leg: B={B} x L={L}, no clip / AdamW; GPU line: B=4 x L=1024 with "
+                                              "them -- context only, do not divide the two"}
 
 
 # ---------------------------------------------------------------------------------------------------- traffic record
