@@ -255,8 +255,10 @@ int srn_style_token_attention_kv(const float* ref, const float* wq_t, const floa
  * parity unpinned).  The STFT itself is srn_conv_gemm over the reflect-padded signal viewed as rows of 16 samples with
  * the window x DFT basis as weights; its output rows are [re(0..n_bins-1) | im(0..n_bins-1) | pad] with stride ld.
  */
-/* numpy.pad(x, pad, mode="reflect") per batch row, zero-filled up to ld: x (B, n) -> out (B, ld). */
-int srn_reflect_pad(const float* x, float* out, int B, int n, int pad, int ld, void* stream);
+/* numpy.pad(x, pad, mode) per batch row, zero-filled up to ld: x (B, n) -> out (B, ld).  mode 0 = "reflect" (what
+ * logmelfilterbank passes to librosa.stft, preprocess.py:174-181), 1 = "constant" zeros (librosa.stft's default since
+ * 0.10, which loudness_extract's call preprocess.py:131 takes). */
+int srn_pad_signal(const float* x, float* out, int B, int n, int pad, int ld, int mode, void* stream);
 /* out (frames, n_mels) = log_b(max(eps, |spec| @ mel^T)); mel_t (n_bins, n_mels) = filterbank transposed;
  * log_mode 10 / 2 / 0 (natural)  (preprocess.py:176-203). */
 int srn_logmel(const float* spec, const float* mel_t, float* out, int64_t frames, int n_bins, int ld, int n_mels,

@@ -5,8 +5,9 @@ recipe's analysis settings (egs/gtsinger/ssc1/conf/serenade.yaml:4-21: 24 kHz, f
 
 **PARITY UNPINNED.**  The reference delegates all of this arithmetic to `librosa` (un-vendored; `setup.cfg` lists it
 without a pin), which is not installed in the build container, and the reference holds no fixture for these functions.
-What follows restates librosa's published behaviour (0.10.x: `stft` with center / reflect padding and a periodic Hann
-window zero-padded to n_fft, `filters.mel` with the Slaney scale and Slaney area normalisation, `power_to_db` with
+What follows restates librosa's published behaviour (0.10.x: `stft` with center padding -- pad_mode "reflect" where the
+call site passes it (logmelfilterbank, preprocess.py:180), the library default elsewhere (loudness_extract, :131):
+"constant" zeros since 0.10, "reflect" before -- and a periodic Hann window zero-padded to n_fft, `filters.mel` with the Slaney scale and Slaney area normalisation, `power_to_db` with
 ref 1.0 / amin 1e-10 / top_db 80, `A_weighting`, `db_to_amplitude`) anchored on the reference's call sites
 preprocess.py:130-137 and :176-199.  It is cross-checked in tests/ against independent formulas (a direct DFT,
 scipy's window, the filterbank's partition-of-unity / area properties), never against librosa itself.
@@ -23,13 +24,13 @@ def hann_periodic(win_length):
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)
 
 
-def stft(audio, n_fft, hop_length, win_length=None):
+def stft(audio, n_fft, hop_length, win_length=None, pad_mode="reflect"):
     """(1 + n_fft // 2, 1 + len(audio) // hop_length) complex128"""
     win_length = n_fft if win_length is None else win_length
     w = np.zeros(n_fft)
     lpad = (n_fft - win_length) // 2  # util.pad_center
     w[lpad:lpad + win_length] = hann_periodic(win_length)
-    y = np.pad(np.asarray(audio, dtype=np.float64), n_fft // 2, mode="reflect")
+    y = np.pad(np.asarray(audio, dtype=np.float64), n_fft // 2, mode=pad_mode)
     n_frames = 1 + (len(y) - n_fft) // hop_length
     idx = np.arange(n_fft)[None, :] + hop_length * np.arange(n_frames)[:, None]
     return np.fft.rfft(y[idx] * w[None, :], axis=1).T
@@ -92,9 +93,10 @@ def a_weighting(frequencies, min_db=-80.0):
     return np.maximum(min_db, w)
 
 
-def loudness_extract(audio, sampling_rate, hop_length, n_fft=2048):
-    """-> (#frames,) log mean A-weighted amplitude.  librosa.stft / fft_frequencies defaults: n_fft = 2048."""
-    power = np.abs(stft(audio, n_fft, hop_length)) ** 2  # (bins, frames)
+def loudness_extract(audio, sampling_rate, hop_length, n_fft=2048, pad_mode="constant"):
+    """-> (#frames,) log mean A-weighted amplitude.  librosa.stft / fft_frequencies defaults: n_fft = 2048 and, since
+    librosa 0.10, zero ("constant") padding of the centred frames; pad_mode="reflect" is the pre-0.10 default."""
+    power = np.abs(stft(audio, n_fft, hop_length, pad_mode=pad_mode)) ** 2  # (bins, frames)
     bins = np.linspace(0.0, sampling_rate / 2.0, 1 + n_fft // 2)
     db = 10.0 * np.log10(np.maximum(1e-10, power))       # power_to_db(ref=1.0, amin=1e-10, top_db=80.0)
     db = np.maximum(db, db.max() - 80.0)

@@ -99,7 +99,7 @@ _SIGS = {
     "srn_conv2d_bn_relu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_gru_last": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "srn_style_token_attention": (c_int, [_P] * 11 + [c_int] * 6 + [_P]),
-    "srn_reflect_pad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "srn_pad_signal": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_logmel": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, c_float, c_int, _P]),
     "srn_loudness": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P]),
     "srn_gru_recur_last": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -110,7 +110,7 @@ class DecodeJob:
         with open(cfg_path) as f:
             self.config = yaml.load(f, Loader=yaml.Loader)
         self.config.update(vars(args))  # command line wins, as in the reference (ssc_decode.py:287-289)
-        self.styles = None
+        self.styles, self._sharded = None, False
         if args.ref_dict is not None:
             with open(args.ref_dict) as f:
                 self.styles = json.load(f)
@@ -178,7 +178,8 @@ class DecodeJob:
                 continue
             logging.info(f"  style {style}")
             ref = self.prompt(path)
-            write_wav_pcm16(os.path.join(out, f"00_{style}_reference.wav"), ref["wave"], self.sr)
+            if not self._sharded:  # several ranks: rank 0 wrote every prompt's audio once, up front (run())
+                write_wav_pcm16(os.path.join(out, f"00_{style}_reference.wav"), ref["wave"], self.sr)
             # NB: linear_midi_shift edits item["lf0"] in place, so later styles start from the shifted contour --
             # the reference behaves the same way (ssc_decode.py:424); snapshot what it would write for this style
             lf0 = linear_midi_shift(item["lf0"], ref["f0"]).astype(np.float32)
@@ -222,6 +223,16 @@ class DecodeJob:
 
     def run(self):
         rank, world = parallel.rank_world()
+        self._sharded = world > 1
+        if self._sharded:
+            # one run = one set of prompts: a per-rank random draw would convert with different prompts on different
+            # ranks and leave whichever 00_*_reference.wav was written last (the reference draws once per run)
+            if self.styles is None:
+                raise ValueError("several ranks need --ref-dict: random prompts are drawn per process")
+            if rank == 0:
+                for style, path in self.styles.items():
+                    write_wav_pcm16(os.path.join(self.args.outdir, f"00_{style}_reference.wav"),
+                                    read_feats(path, "wave"), self.sr)
         lo, hi = parallel.shard_range(len(self.dataset), rank, world)
         frames, t0 = 0, time.time()
         n_utt = max(1, int(self.args.batch_utterances))

@@ -14,17 +14,18 @@
 namespace {
 
 // out[b][i] = x[b][reflect(i - pad)] for i < n + 2 pad, 0 up to ld (numpy.pad mode="reflect": no edge repeat)
-__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          const int n, const int pad, const int ld) {
+__global__ __launch_bounds__(256) void pad_signal_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                        const int n, const int pad, const int ld, const int zero) {
   const int b = blockIdx.y;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < ld; i += gridDim.x * 256) {
     float v = 0.f;
     if (i < n + 2 * pad) {
       int j = i - pad;
+      const bool outside = j < 0 || j >= n;
       if (j < 0) j = -j;
       if (j >= n) j = 2 * (n - 1) - j;
       j = min(max(j, 0), n - 1);
-      v = x[(int64_t)b * n + j];
+      v = (zero && outside) ? 0.f : x[(int64_t)b * n + j];
     }
     out[(int64_t)b * ld + i] = v;
   }
@@ -49,6 +50,13 @@ __global__ __launch_bounds__(128) void logmel_kernel(const float* __restrict__ s
     a = fmaxf(a, eps);
     out[fr * n_mels + m] = log_mode == 10 ? log10f(a) : (log_mode == 2 ? log2f(a) : logf(a));
   }
+}
+
+// zero-fill by a kernel: a hipMemsetAsync node captured into a hipGraph replays with a corrupted fill value from the
+// second replay on on this ROCm stack (profiles/r3_graph_probe_*.json), so nothing in this library issues one
+__global__ void zero_u32_kernel(unsigned* __restrict__ p, const int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
 }
 
 // per-utterance maximum of the power spectrogram (non-negative floats order like their bit patterns, so an integer
@@ -91,11 +99,13 @@ __global__ __launch_bounds__(256) void loudness_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int srn_reflect_pad(const float* x, float* out, int B, int n, int pad, int ld, void* stream) {
-  SRN_CHECK_ARG(x && out && B > 0 && n > 1 && pad >= 0 && pad < n && ld >= n + 2 * pad, "reflect_pad: bad args");
+extern "C" int srn_pad_signal(const float* x, float* out, int B, int n, int pad, int ld, int mode, void* stream) {
+  SRN_CHECK_ARG(x && out && B > 0 && n > 1 && pad >= 0 && ld >= n + 2 * pad && (mode == 0 || mode == 1),
+                "pad_signal: bad args");
+  SRN_CHECK_ARG(mode == 1 || pad < n, "pad_signal: reflect padding of %d needs more than %d samples", pad, n);
   int bx = (ld + 255) / 256;
   bx = bx > 4096 ? 4096 : bx;
-  hipLaunchKernelGGL(reflect_pad_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x, out, n, pad, ld);
+  hipLaunchKernelGGL(pad_signal_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, x, out, n, pad, ld, mode);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -116,7 +126,7 @@ extern "C" int srn_loudness(const float* spec, const float* a_weight_db, unsigne
   SRN_CHECK_ARG(spec && a_weight_db && gmax_ws && out && B > 0 && frames > 0 && n_bins > 0 && ld >= 2 * n_bins,
                 "loudness: bad args");
   hipStream_t st = (hipStream_t)stream;
-  SRN_CHECK_HIP(hipMemsetAsync(gmax_ws, 0, sizeof(unsigned) * B, st));
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((B + 255) / 256), dim3(256), 0, st, gmax_ws, B);
   hipLaunchKernelGGL(power_max_kernel, dim3(frames < 512 ? frames : 512, B), dim3(256), 0, st, spec, gmax_ws, frames,
                      n_bins, ld);
   hipLaunchKernelGGL(loudness_kernel, dim3(frames, B), dim3(256), 0, st, spec, a_weight_db, gmax_ws, out, frames,

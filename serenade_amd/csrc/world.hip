@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int NT = 256;  // threads per frame
+// threads per frame (template parameter NT of the frame kernels): CheapTrick 256 (three short transforms, 48 KB of
+// LDS, three frames per CU), D4C 512 (107 KB: one frame per CU, so its eight waves are all the latency hiding there
+// is -- measured 8.0 -> 6.0 ms per 16 392 frames against 256)
+constexpr int NT_CHEAPTRICK = 256, NT_D4C = 512, NT_F0 = 256;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kSafeGuard = 1e-12;                        // world::kMySafeGuardMinimum
 constexpr double kNoiseAfterSmoothing = 1.7716279188122702e-16;  // world::kEps * sqrt(2 / pi): E|randn| * eps
@@ -24,7 +27,8 @@ constexpr double kNoiseAfterSmoothing = 1.7716279188122702e-16;  // world::kEps 
 __device__ __forceinline__ int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// sum over the workgroup, result in every thread; `red` holds NT/64 doubles.
+// sum over the workgroup, result in every thread; `red` holds NT / 64 doubles.
+template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* red) {
   v = wave_sum_d(v);
   __syncthreads();
@@ -38,7 +42,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 // In-place radix-2 decimation-in-time FFT of N = 2^LOG2N complex points held as two LDS planes.  Input in
 // bit-reversed order, output in natural order; tw = N/2 pairs (cos, -sin)(2 pi m / N) in LDS.
-template <int LOG2N>
+template <int LOG2N, int NT>
 __device__ void fft_lds(double* re, double* im, const double* tw) {
   constexpr int N = 1 << LOG2N;
 #pragma unroll 1
@@ -73,7 +77,7 @@ enum { WIN_CHEAPTRICK = 0, WIN_HANNING = 1, WIN_BLACKMAN = 2 };
 // and leaves the frame in (re, im) in bit-reversed order -- im = (n + 1) * re when `ramp` (D4C's centroid transforms
 // the frame and its time-weighted copy; both ride in ONE complex FFT), else 0.  scr: 2N doubles of scratch.
 // Returns the number of windowed samples, or 0 when unit energy was requested on an all-zero frame.
-template <int LOG2N>
+template <int LOG2N, int NT>
 __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, double f0, double position, int kind,
                               double ratio, bool unit_energy, bool ramp, double* re, double* im, double* scr,
                               double* red) {
@@ -99,7 +103,7 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
     ww += w * w;
   }
   double wnorm = 1.0;  // CheapTrick's window has unit energy; D4C's windows are used as they are
-  if (kind == WIN_CHEAPTRICK) wnorm = sqrt(block_sum(ww, red));
+  if (kind == WIN_CHEAPTRICK) wnorm = sqrt(block_sum<NT>(ww, red));
   double sw = 0.0, sxw = 0.0;
   for (int j = threadIdx.x; j < n; j += NT) {
     const double w = scr[j] / wnorm;
@@ -109,8 +113,8 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
     sw += w;
     sxw += v;
   }
-  sw = block_sum(sw, red);
-  sxw = block_sum(sxw, red);
+  sw = block_sum<NT>(sw, red);
+  sxw = block_sum<NT>(sxw, red);
   const double coef = sxw / sw;
   double pw = 0.0;
   for (int j = threadIdx.x; j < n; j += NT) {
@@ -120,7 +124,7 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
   }
   double escale = 1.0;
   if (unit_energy) {
-    pw = block_sum(pw, red);
+    pw = block_sum<NT>(pw, red);
     if (!(pw > 0.0)) return 0;
     escale = sqrt(pw);
   }
@@ -146,6 +150,7 @@ __device__ __forceinline__ double interp1q(double x0, double shift, const double
 }
 
 // DCCorrection (common.cpp): the power below F0 gets the mirror image of the power between F0 and 0 added.
+template <int NT>
 __device__ void dc_correction(double* a, int half, double f0, int fs, int N, double* scr) {
   int upper = 2 + (int)(f0 * N / fs);
   upper = clampi(upper, 2, half);
@@ -159,6 +164,7 @@ __device__ void dc_correction(double* a, int half, double f0, int fs, int N, dou
 }
 
 // inclusive prefix sum of a[0..M) in place
+template <int NT>
 __device__ void block_cumsum(double* a, int M, double* red) {
   const int per = (M + NT - 1) / NT;
   const int lo = min((int)threadIdx.x * per, M), hi = min(lo + per, M);
@@ -185,6 +191,7 @@ __device__ void block_cumsum(double* a, int M, double* red) {
 
 // LinearSmoothing (common.cpp): mean of the (mirrored, piecewise-constant) spectrum over [f - width/2, f + width/2]
 // as a difference of its running integral.  in -> out (may alias), both half+1 long; scr: half + 2*boundary + 1.
+template <int NT>
 __device__ void linear_smoothing(const double* in, double* out, int half, double width, int fs, int N, double add,
                                  double* scr, double* red) {
   int boundary = (int)(width * N / fs) + 1;
@@ -200,7 +207,7 @@ __device__ void linear_smoothing(const double* in, double* out, int half, double
     scr[m] = v * fs / N;
   }
   __syncthreads();
-  block_cumsum(scr, M, red);
+  block_cumsum<NT>(scr, M, red);
   const double origin = -(boundary - 0.5) * fs / N;
   for (int k = threadIdx.x; k <= half; k += NT) {
     const double ax = (double)k / N * fs - width / 2.0;
@@ -231,14 +238,14 @@ __device__ __forceinline__ Frame load_frame(const SrnWorldParams& p) {
   return fr;
 }
 
-template <int LOG2N>
+template <int LOG2N, int NT>
 __device__ __forceinline__ void load_twiddles(const double* __restrict__ g, double* tw) {
   constexpr int N = 1 << LOG2N;
   for (int i = threadIdx.x; i < N; i += NT) tw[i] = g[i];
 }
 
 // ------------------------------------------------------------------------------------------------ CheapTrick
-template <int LOG2N>
+template <int LOG2N, int NT>
 __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) {
   constexpr int N = 1 << LOG2N, HALF = N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds_w[];
@@ -247,21 +254,21 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
   double* tw = im + N;           // N   (N/2 pairs)
   double* scr = tw + N;          // 2N
   double* pw = scr + 2 * N;      // HALF + 1
-  double* red = pw + HALF + 1;   // 8
+  double* red = pw + HALF + 1;   // 2 NT / 64
   const Frame fr = load_frame(p);
   if (!fr.valid) return;
-  load_twiddles<LOG2N>(p.twiddle, tw);
+  load_twiddles<LOG2N, NT>(p.twiddle, tw);
   const int fs = p.fs;
   // f0 at or below the floor (and anything that is not a usable F0) is analysed as kDefaultF0 (cheaptrick.cpp)
   double f0 = fr.f0 <= p.f0_floor ? 500.0 : fr.f0;
   if (!(f0 < 0.25 * fs)) f0 = 0.25 * fs;
-  const int n = windowed_frame<LOG2N>(fr.x, fr.x_len, fs, f0, fr.t, WIN_CHEAPTRICK, 0.0, false, false, re, im, scr, red);
-  fft_lds<LOG2N>(re, im, tw);
+  const int n = windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, fr.t, WIN_CHEAPTRICK, 0.0, false, false, re, im, scr, red);
+  fft_lds<LOG2N, NT>(re, im, tw);
   // power spectrum (+ the expected power of WORLD's 1e-12 * randn() safeguard) with DC correction
   const double floor_power = n * kSafeGuard * kSafeGuard;
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = re[k] * re[k] + im[k] * im[k] + floor_power;
-  dc_correction(pw, HALF, f0, fs, N, scr);
-  linear_smoothing(pw, pw, HALF, f0 * 2.0 / 3.0, fs, N, kNoiseAfterSmoothing, scr, red);
+  dc_correction<NT>(pw, HALF, f0, fs, N, scr);
+  linear_smoothing<NT>(pw, pw, HALF, f0 * 2.0 / 3.0, fs, N, kNoiseAfterSmoothing, scr, red);
   // cepstrum of the symmetric log spectrum
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = log(pw[k]);
   __syncthreads();
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
     re[r] = pw[j <= HALF ? j : N - j];
     im[r] = 0.0;
   }
-  fft_lds<LOG2N>(re, im, tw);
+  fft_lds<LOG2N, NT>(re, im, tw);
   // smoothing lifter sinc(f0 q) and compensation lifter (1 - 2 q1) + 2 q1 cos(2 pi f0 q), then / N
   const double q1 = p.q1;
   double* ceps = p.out1 ? p.out1 + (int64_t)blockIdx.y * p.out1_bs + (int64_t)blockIdx.x * p.ld_out1 : nullptr;
@@ -293,13 +300,14 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
     re[r] = pw[j <= HALF ? j : N - j];
     im[r] = 0.0;
   }
-  fft_lds<LOG2N>(re, im, tw);
+  fft_lds<LOG2N, NT>(re, im, tw);
   double* sp = p.out0 + (int64_t)blockIdx.y * p.out0_bs + (int64_t)blockIdx.x * p.ld_out0;
   for (int k = threadIdx.x; k <= HALF; k += NT) sp[k] = exp(re[k]);
 }
 
 // ------------------------------------------------------------------------------------------------ D4C
 // ascending bitonic sort of a[0..n), n a power of two
+template <int NT>
 __device__ void bitonic_sort(double* a, int n) {
   for (int k = 2; k <= n; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -319,7 +327,7 @@ __device__ void bitonic_sort(double* a, int n) {
   __syncthreads();
 }
 
-template <int LOG2N>
+template <int LOG2N, int NT>
 __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
   constexpr int N = 1 << LOG2N, HALF = N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds_w[];
@@ -330,7 +338,8 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
   double* cen = scr + 2 * N;       // HALF + 1
   double* pw = cen + HALF + 1;     // HALF + 1
   double* gd = pw + HALF + 1;      // HALF + 1
-  double* red = gd + HALF + 1;     // 8
+  double* red = gd + HALF + 1;     // 2 NT / 64
+  constexpr int NW = NT / 64;
   __shared__ int s_arg;
   const Frame fr = load_frame(p);
   if (!fr.valid) return;
@@ -342,14 +351,14 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
     if (threadIdx.x < n_bands) out[threadIdx.x] = unvoiced;
     return;
   }
-  load_twiddles<LOG2N>(p.twiddle, tw);
+  load_twiddles<LOG2N, NT>(p.twiddle, tw);
   double f0 = fr.f0 < 0.25 * fs ? fr.f0 : 0.25 * fs;
 
   // ---- D4C Love Train: share of the 100 Hz .. 4 kHz power in 100 Hz .. 7.9 kHz, Blackman window of 3 periods
   {
     const double cur = fmax(f0, 40.0);
-    windowed_frame<LOG2N>(fr.x, fr.x_len, fs, cur, fr.t, WIN_BLACKMAN, 3.0, false, false, re, im, scr, red);
-    fft_lds<LOG2N>(re, im, tw);
+    windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, cur, fr.t, WIN_BLACKMAN, 3.0, false, false, re, im, scr, red);
+    fft_lds<LOG2N, NT>(re, im, tw);
     const int b0 = (int)ceil(100.0 * N / fs), b1 = (int)ceil(4000.0 * N / fs), b2 = (int)ceil(7900.0 * N / fs);
     double s1 = 0.0, s2 = 0.0;
     for (int k = b0 + 1 + threadIdx.x; k <= min(b2, HALF); k += NT) {
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
       s2 += v;
       if (k <= b1) s1 += v;
     }
-    s1 = block_sum(s1, red);
-    s2 = block_sum(s2, red);
+    s1 = block_sum<NT>(s1, red);
+    s2 = block_sum<NT>(s2, red);
     if (!(s2 > 0.0) || s1 / s2 <= p.threshold) {
       if (threadIdx.x < n_bands) out[threadIdx.x] = unvoiced;
       return;
@@ -370,12 +379,12 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
   for (int k = threadIdx.x; k <= HALF; k += NT) cen[k] = 0.0;
   for (int side = 0; side < 2; ++side) {
     const double pos = fr.t + (side == 0 ? -0.25 : 0.25) / f0;
-    const int n = windowed_frame<LOG2N>(fr.x, fr.x_len, fs, f0, pos, WIN_BLACKMAN, 4.0, true, true, re, im, scr, red);
+    const int n = windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, pos, WIN_BLACKMAN, 4.0, true, true, re, im, scr, red);
     if (n == 0) {  // digital silence under a voiced F0: no periodicity to measure
       if (threadIdx.x < n_bands) out[threadIdx.x] = unvoiced;
       return;
     }
-    fft_lds<LOG2N>(re, im, tw);
+    fft_lds<LOG2N, NT>(re, im, tw);
     // Z = S1 + i S2 (S1: frame, S2: time-weighted frame): S1 = (Z[k] + conj Z[N-k]) / 2, S2 = (Z[k] - conj Z[N-k]) / 2i
     for (int k = threadIdx.x; k <= HALF; k += NT) {
       const int m = (N - k) & (N - 1);
@@ -387,19 +396,19 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
     }
     __syncthreads();
   }
-  dc_correction(cen, HALF, f0, fs, N, scr);
+  dc_correction<NT>(cen, HALF, f0, fs, N, scr);
 
   // ---- smoothed power spectrum: Hanning window of 4 periods, DC correction, smoothing over one F0
-  windowed_frame<LOG2N>(fr.x, fr.x_len, fs, f0, fr.t, WIN_HANNING, 4.0, false, false, re, im, scr, red);
-  fft_lds<LOG2N>(re, im, tw);
+  windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, fr.t, WIN_HANNING, 4.0, false, false, re, im, scr, red);
+  fft_lds<LOG2N, NT>(re, im, tw);
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = re[k] * re[k] + im[k] * im[k];
-  dc_correction(pw, HALF, f0, fs, N, scr);
-  linear_smoothing(pw, pw, HALF, f0, fs, N, 0.0, scr, red);
+  dc_correction<NT>(pw, HALF, f0, fs, N, scr);
+  linear_smoothing<NT>(pw, pw, HALF, f0, fs, N, 0.0, scr, red);
 
   // ---- static group delay minus its own smoothed version
   for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] = cen[k] / pw[k];
-  linear_smoothing(gd, gd, HALF, f0 / 2.0, fs, N, 0.0, scr, red);
-  linear_smoothing(gd, cen, HALF, f0, fs, N, 0.0, scr, red);
+  linear_smoothing<NT>(gd, gd, HALF, f0 / 2.0, fs, N, 0.0, scr, red);
+  linear_smoothing<NT>(gd, cen, HALF, f0, fs, N, 0.0, scr, red);
   for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] -= cen[k];
   __syncthreads();
 
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
       re[r] = (j < wl && src >= 0 && src <= HALF) ? gd[src] * p.band_window[j] : 0.0;
       im[r] = 0.0;
     }
-    fft_lds<LOG2N>(re, im, tw);
+    fft_lds<LOG2N, NT>(re, im, tw);
     // powers into scr[0..HALF]; the largest one is taken out so that HALF (a power of two) values get sorted
     double best = -1.0;
     int arg = 0;
@@ -440,28 +449,28 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
       red[threadIdx.x >> 6] = best;
-      red[4 + (threadIdx.x >> 6)] = (double)arg;
+      red[NW + (threadIdx.x >> 6)] = (double)arg;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       int w = 0;
-      for (int i = 1; i < NT / 64; ++i)
+      for (int i = 1; i < NW; ++i)
         if (red[i] > red[w]) w = i;
-      s_arg = (int)red[4 + w];
+      s_arg = (int)red[NW + w];
     }
     __syncthreads();
     const int amax = s_arg;
     const double vmax = scr[amax];
     __syncthreads();
     if (threadIdx.x == 0) scr[amax] = scr[HALF];  // drop the maximum: HALF values remain in scr[0..HALF)
-    bitonic_sort(scr, HALF);
+    bitonic_sort<NT>(scr, HALF);
     double small = 0.0, rest = 0.0;
     for (int k = threadIdx.x; k < HALF; k += NT) {
       if (k < n_small) small += scr[k];
       else rest += scr[k];
     }
-    small = block_sum(small, red);
-    rest = block_sum(rest, red);
+    small = block_sum<NT>(small, red);
+    rest = block_sum<NT>(rest, red);
     const double coarse = 10.0 * log10(small / (small + rest + vmax)) + (f0 - 100.0) / 50.0;
     if (threadIdx.x == 0) out[band] = fmin(0.0, coarse);
     __syncthreads();
@@ -472,12 +481,12 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
 // out[r, k] = sum_q mat_t[q, k] * g(in[r, q]), g = log or identity: sp2mc as ONE matrix (irfft, c0 / 2 and SPTK's
 // freqt recursion are linear), and the same for the liftered cepstrum CheapTrick leaves behind.
 constexpr int PR = 8;  // rows per workgroup
-__global__ __launch_bounds__(NT) void project_kernel(const double* __restrict__ in, int64_t rows, int K, int ld_in,
+__global__ __launch_bounds__(256) void project_kernel(const double* __restrict__ in, int64_t rows, int K, int ld_in,
                                                      const double* __restrict__ mat_t, int n_out, int take_log,
                                                      double* __restrict__ out, int ld_out) {
   extern __shared__ __attribute__((aligned(16))) double lds_p[];  // PR x K
   const int64_t r0 = (int64_t)blockIdx.x * PR;
-  for (int i = threadIdx.x; i < PR * K; i += NT) {
+  for (int i = threadIdx.x; i < PR * K; i += 256) {
     const int r = i / K, q = i - r * K;
     double v = 0.0;
     if (r0 + r < rows) {
@@ -562,7 +571,7 @@ __global__ void f0_match_length_kernel(const double* __restrict__ in, int64_t in
 // convert_continuos_f0 (ssc_postprocessing.py:51-72): hold the first / last voiced value outwards, join voiced frames
 // linearly (scipy interp1d: slope * (x - x_lo) + y_lo with x_lo the last voiced frame strictly before x).
 // One workgroup per item; ok[b] = 0 when every frame is unvoiced (cf0 = f0 then).
-__global__ __launch_bounds__(NT) void cont_f0_kernel(const double* __restrict__ f0, int64_t bs,
+__global__ __launch_bounds__(NT_F0) void cont_f0_kernel(const double* __restrict__ f0, int64_t bs,
                                                      const int* __restrict__ n_frames, double* __restrict__ cf0,
                                                      float* __restrict__ uv, int* __restrict__ ok) {
 #pragma clang fp contract(off)
@@ -578,7 +587,7 @@ __global__ __launch_bounds__(NT) void cont_f0_kernel(const double* __restrict__ 
   }
   __syncthreads();
   int first = n, last = -1;
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = threadIdx.x; i < n; i += NT_F0) {
     const bool v = y[i] != 0.0;
     u[i] = v ? 1.0f : 0.0f;
     if (v) {
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(NT) void cont_f0_kernel(const double* __restrict__ 
   first = s_first;
   last = s_last;
   if (last < 0) {
-    for (int i = threadIdx.x; i < n; i += NT) o[i] = y[i];
+    for (int i = threadIdx.x; i < n; i += NT_F0) o[i] = y[i];
     if (threadIdx.x == 0) ok[b] = 0;
     return;
   }
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(NT) void cont_f0_kernel(const double* __restrict__ 
   // interpolation nodes: every frame up to `first` (holding y[first]), every voiced frame, every frame from `last` on
   auto is_node = [&](int j) { return j <= first || j >= last || y[j] != 0.0; };
   auto value = [&](int j) { return j < first ? y[first] : (j >= last ? y[last] : y[j]); };
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = threadIdx.x; i < n; i += NT_F0) {
     double v;
     if (n < 2) {
       v = value(i);
@@ -619,10 +628,10 @@ __global__ __launch_bounds__(NT) void cont_f0_kernel(const double* __restrict__ 
 
 // exclusive prefix over frames of hop * radius, radius = fl32(fl32(f0) / fs) % 1: SignalGenerator's per-sample cumsum
 // restricted to frame starts (the samples of one frame share one radius).  One workgroup per item.
-__global__ __launch_bounds__(NT) void sine_phase_kernel(const double* __restrict__ f0, int64_t bs,
+__global__ __launch_bounds__(NT_F0) void sine_phase_kernel(const double* __restrict__ f0, int64_t bs,
                                                         const int* __restrict__ n_frames, int fs, int hop,
                                                         double* __restrict__ phase) {
-  __shared__ double red[NT / 64];
+  __shared__ double red[NT_F0 / 64];
   __shared__ double s_carry;
   const int b = blockIdx.x;
   const int n = n_frames[b];
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(NT) void sine_phase_kernel(const double* __restrict
   if (threadIdx.x == 0) s_carry = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int base = 0; base < n; base += NT) {
+  for (int base = 0; base < n; base += NT_F0) {
     const int i = base + threadIdx.x;
     double v = 0.0;
     if (i < n) {
@@ -650,7 +659,7 @@ __global__ __launch_bounds__(NT) void sine_phase_kernel(const double* __restrict
     for (int k = 0; k < w; ++k) run += red[k];
     if (i < n) o[i] = run;
     __syncthreads();
-    if (threadIdx.x == NT - 1) s_carry = run + v;
+    if (threadIdx.x == NT_F0 - 1) s_carry = run + v;
     __syncthreads();
   }
 }
@@ -700,7 +709,9 @@ __global__ void excitation_kernel(ExcArgs a, int64_t bs, const int* __restrict__
   }
 }
 
-int world_lds_bytes(int N, int planes_half) { return (int)sizeof(double) * (5 * N + planes_half * (N / 2 + 1) + 8); }
+int world_lds_bytes(int N, int planes_half, int nt) {
+  return (int)sizeof(double) * (5 * N + planes_half * (N / 2 + 1) + 2 * (nt / 64));
+}
 
 int check_world(const SrnWorldParams* p, const char* who) {
   SRN_CHECK_ARG(p != nullptr, "%s: null params", who);
@@ -728,21 +739,21 @@ extern "C" int srn_world_cheaptrick(const SrnWorldParams* p, void* stream) {
   static SrnSmemAttr a9, a10, a11;
   switch (p->fft_size) {
     case 512: {
-      const int lds = world_lds_bytes(512, 1);
-      if (int rc = a9.ensure((const void*)cheaptrick_kernel<9>, lds)) return rc;
-      hipLaunchKernelGGL(cheaptrick_kernel<9>, grid, dim3(NT), lds, st, *p);
+      const int lds = world_lds_bytes(512, 1, NT_CHEAPTRICK);
+      if (int rc = a9.ensure((const void*)(cheaptrick_kernel<9, NT_CHEAPTRICK>), lds)) return rc;
+      hipLaunchKernelGGL((cheaptrick_kernel<9, NT_CHEAPTRICK>), grid, dim3(NT_CHEAPTRICK), lds, st, *p);
       break;
     }
     case 1024: {
-      const int lds = world_lds_bytes(1024, 1);
-      if (int rc = a10.ensure((const void*)cheaptrick_kernel<10>, lds)) return rc;
-      hipLaunchKernelGGL(cheaptrick_kernel<10>, grid, dim3(NT), lds, st, *p);
+      const int lds = world_lds_bytes(1024, 1, NT_CHEAPTRICK);
+      if (int rc = a10.ensure((const void*)(cheaptrick_kernel<10, NT_CHEAPTRICK>), lds)) return rc;
+      hipLaunchKernelGGL((cheaptrick_kernel<10, NT_CHEAPTRICK>), grid, dim3(NT_CHEAPTRICK), lds, st, *p);
       break;
     }
     case 2048: {
-      const int lds = world_lds_bytes(2048, 1);
-      if (int rc = a11.ensure((const void*)cheaptrick_kernel<11>, lds)) return rc;
-      hipLaunchKernelGGL(cheaptrick_kernel<11>, grid, dim3(NT), lds, st, *p);
+      const int lds = world_lds_bytes(2048, 1, NT_CHEAPTRICK);
+      if (int rc = a11.ensure((const void*)(cheaptrick_kernel<11, NT_CHEAPTRICK>), lds)) return rc;
+      hipLaunchKernelGGL((cheaptrick_kernel<11, NT_CHEAPTRICK>), grid, dim3(NT_CHEAPTRICK), lds, st, *p);
       break;
     }
     default:
@@ -771,13 +782,13 @@ extern "C" int srn_world_d4c(const SrnWorldParams* p, void* stream) {
   dim3 grid(p->max_frames, p->n_batch);
   hipStream_t st = (hipStream_t)stream;
   static SrnSmemAttr a10, a11;
-  const int lds = world_lds_bytes(N, 3);
+  const int lds = world_lds_bytes(N, 3, NT_D4C);
   if (N == 1024) {
-    if (int rc = a10.ensure((const void*)d4c_kernel<10>, lds)) return rc;
-    hipLaunchKernelGGL(d4c_kernel<10>, grid, dim3(NT), lds, st, *p);
+    if (int rc = a10.ensure((const void*)(d4c_kernel<10, NT_D4C>), lds)) return rc;
+    hipLaunchKernelGGL((d4c_kernel<10, NT_D4C>), grid, dim3(NT_D4C), lds, st, *p);
   } else {
-    if (int rc = a11.ensure((const void*)d4c_kernel<11>, lds)) return rc;
-    hipLaunchKernelGGL(d4c_kernel<11>, grid, dim3(NT), lds, st, *p);
+    if (int rc = a11.ensure((const void*)(d4c_kernel<11, NT_D4C>), lds)) return rc;
+    hipLaunchKernelGGL((d4c_kernel<11, NT_D4C>), grid, dim3(NT_D4C), lds, st, *p);
   }
   SRN_CHECK_LAUNCH();
   return 0;
@@ -791,7 +802,7 @@ extern "C" int srn_world_project(const double* in, int64_t rows, int K, int ld_i
   const int lds = PR * K * (int)sizeof(double);
   static SrnSmemAttr attr;
   if (int rc = attr.ensure((const void*)project_kernel, PR * 2049 * (int)sizeof(double))) return rc;
-  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((rows + PR - 1) / PR)), dim3(NT), lds, (hipStream_t)stream, in,
+  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((rows + PR - 1) / PR)), dim3(256), lds, (hipStream_t)stream, in,
                      rows, K, ld_in, mat_t, n_out, take_log, out, ld_out);
   SRN_CHECK_LAUNCH();
   return 0;
@@ -829,7 +840,7 @@ extern "C" int srn_f0_match_length(const double* in, int64_t in_bs, const int32_
 extern "C" int srn_cont_f0(const double* f0, int64_t bs, const int32_t* n_frames, double* cf0, float* uv, int32_t* ok,
                            int n_batch, void* stream) {
   SRN_CHECK_ARG(f0 && n_frames && cf0 && uv && ok && n_batch > 0, "srn_cont_f0: bad args");
-  hipLaunchKernelGGL(cont_f0_kernel, dim3(n_batch), dim3(NT), 0, (hipStream_t)stream, f0, bs, n_frames, cf0, uv, ok);
+  hipLaunchKernelGGL(cont_f0_kernel, dim3(n_batch), dim3(NT_F0), 0, (hipStream_t)stream, f0, bs, n_frames, cf0, uv, ok);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -856,7 +867,7 @@ extern "C" int srn_sifigan_excitation(const SrnExcitationParams* p, void* stream
                     "srn_sifigan_excitation: dilated-factor track %d", i);
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sine_phase_kernel, dim3(p->n_batch), dim3(NT), 0, st, p->f0, p->f_bs, p->n_frames, p->fs, p->hop,
+  hipLaunchKernelGGL(sine_phase_kernel, dim3(p->n_batch), dim3(NT_F0), 0, st, p->f0, p->f_bs, p->n_frames, p->fs, p->hop,
                      p->phase_ws);
   const int64_t n = (int64_t)p->max_frames * p->hop;
   hipLaunchKernelGGL(excitation_kernel, dim3((unsigned)((n + 255) / 256), p->n_batch), dim3(256), 0, st, a, p->f_bs,

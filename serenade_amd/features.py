@@ -74,7 +74,9 @@ def _a_weight_db(freqs, min_db=-80.0):
 class _Stft:
     """reflect pad + strided implicit-GEMM STFT of (B, n) signals -> self.spec (B, frames, ld) = [re | im | 0]"""
 
-    def __init__(self, dev, B, n, n_fft, hop, win_length):
+    def __init__(self, dev, B, n, n_fft, hop, win_length, pad_mode="reflect"):
+        if pad_mode not in ("reflect", "constant"):
+            raise ValueError(f"pad_mode {pad_mode!r}: 'reflect' or 'constant'")
         c = math.gcd(math.gcd(n_fft, hop), 16)
         if c < 4:
             raise ValueError(f"fft_size {n_fft} and hop_size {hop} must share a factor of 4 (rows of the signal view)")
@@ -87,7 +89,7 @@ class _Stft:
         f = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
         self.audio, self.sig, self.spec = f(B, n), f(B, self.ld_sig), f(B, self.frames, self.ld)
         self.basis = torch.from_numpy(_dft_basis(n_fft, win_length, self.ld)).to(dev)
-        self.ops = [ops.CallOp("srn_reflect_pad", (self.audio, self.sig, B, n, pad, self.ld_sig))]
+        self.ops = [ops.CallOp("srn_pad_signal", (self.audio, self.sig, B, n, pad, self.ld_sig, int(pad_mode == "constant")))]
         # A frame is a contraction over n_fft samples = taps of `cw` samples each.  The signal is viewed as rows that START
         # every c samples (row stride c, so any frame start is a row) but are cw = 32 samples WIDE (overlapping rows are
         # fine for a read-only operand): 32-channel taps take the fast contraction kernel, 16-wide ones the generic one
@@ -153,16 +155,21 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_leng
     return res[0] if single else res
 
 
-def loudness_extract(audio, sampling_rate, hop_length):
+def loudness_extract(audio, sampling_rate, hop_length, pad_mode="constant"):
     """preprocess.py:126-137: (#frames,) log mean A-weighted amplitude (librosa defaults: n_fft 2048, Hann,
-    power_to_db top_db 80 relative to the utterance's loudest bin)."""
+    power_to_db top_db 80 relative to the utterance's loudest bin).
+
+    pad_mode: the reference calls `librosa.stft(audio, hop_length=hop_length)` without a pad_mode, so the edge frames
+    depend on the installed librosa: "constant" (zeros) since librosa 0.10 -- the default here --, "reflect" before
+    (setup.cfg only asks for librosa >= 0.8.0).  Use the mode the `lft` features of a checkpoint were extracted with;
+    about n_fft / 2 / hop frames at each end of an utterance differ between the two."""
     n_fft = 2048
     a, single = _as_batch(audio)
     B, n = a.shape
-    key = ("loud", str(a.device), B, n, sampling_rate, hop_length)
+    key = ("loud", str(a.device), B, n, sampling_rate, hop_length, pad_mode)
 
     def make():
-        st = _Stft(a.device, B, n, n_fft, hop_length, n_fft)
+        st = _Stft(a.device, B, n, n_fft, hop_length, n_fft, pad_mode)
         aw = torch.from_numpy(_a_weight_db(np.linspace(0.0, sampling_rate / 2.0, st.nb)).astype(np.float32)).to(a.device)
         ws = torch.zeros(B, device=a.device, dtype=torch.int32)
         out = torch.zeros(B, st.frames, device=a.device, dtype=torch.float32)

@@ -113,7 +113,12 @@ class ConvOp:
 
 
 def splitk_workspace(device):
-    key = str(device)
+    """the split-K partial-sum slab of the stream that is current while an op is BUILT: ops of one plan run back to
+    back on the stream they were built under, and two streams never share a slab (plans driven from different streams
+    would overwrite each other's partial sums).  Built under a graph capture, the slab comes from the graph's pool
+    and is keyed by the capture stream, so eager code cannot pick it up."""
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (str(device), stream)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
     return _SPLITK_WS[key]

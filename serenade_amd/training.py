@@ -911,31 +911,74 @@ class MultiStepLR:
         self.opt.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
 
     def state_dict(self):
-        return {"milestones": list(self.milestones), "gamma": self.gamma, "base_lr": self.base_lr,
-                "last_epoch": self.last_epoch}
+        """the entries of torch.optim.lr_scheduler.MultiStepLR.state_dict()"""
+        from collections import Counter
+        return {"milestones": Counter(self.milestones), "gamma": self.gamma, "base_lrs": [self.base_lr],
+                "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1,
+                "_get_lr_called_within_step": False, "_last_lr": [self.opt.lr]}
 
     def load_state_dict(self, sd):
-        self.milestones, self.gamma = [int(m) for m in sd["milestones"]], float(sd["gamma"])
-        self.base_lr, self.last_epoch = float(sd["base_lr"]), int(sd["last_epoch"])
+        ms = sd["milestones"]
+        self.milestones = sorted(int(m) for m in (ms.elements() if hasattr(ms, "elements") else ms))
+        self.gamma, self.last_epoch = float(sd["gamma"]), int(sd["last_epoch"])
+        self.base_lr = float(sd["base_lrs"][0] if "base_lrs" in sd else sd["base_lr"])
         self.opt.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
 
 
+def _torch_adamw_state(model, opt):
+    """this optimizer's flat moments as `torch.optim.AdamW.state_dict()` of the reference's optimizer: parameters are
+    numbered in `model.parameters()` order, which is the order of the parameter entries of the state_dict the store
+    was built from (bin/ssc_train.py:331-343 builds AdamW over model.parameters())."""
+    state, ids = {}, []
+    for i, (k, (off, n)) in enumerate(model.spans.items()):
+        shape = model.params[k].shape
+        ids.append(i)
+        if opt.steps > 0:
+            state[i] = {"step": torch.tensor(float(opt.steps)), "exp_avg": opt.m[off:off + n].view(shape).cpu().clone(),
+                        "exp_avg_sq": opt.v[off:off + n].view(shape).cpu().clone()}
+    group = {"lr": opt.lr, "betas": tuple(opt.betas), "eps": opt.eps, "weight_decay": opt.wd, "amsgrad": False,
+             "foreach": None, "maximize": False, "capturable": False, "differentiable": False, "fused": None,
+             "params": ids}
+    return {"state": state, "param_groups": [group]}
+
+
+def _load_torch_adamw_state(o, model, opt):
+    names = list(model.spans)
+    groups = o["param_groups"]
+    ids = [i for g in groups for i in g["params"]]
+    if len(ids) != len(names):
+        raise ValueError(f"optimizer state holds {len(ids)} parameters, this model has {len(names)}")
+    opt.m.zero_(), opt.v.zero_()
+    steps = 0
+    for pos, i in enumerate(ids):
+        st = o["state"].get(i)
+        if st is None:
+            continue
+        off, n = model.spans[names[pos]]
+        if st["exp_avg"].numel() != n:
+            raise ValueError(f"optimizer state {i} has {st['exp_avg'].numel()} elements, {names[pos]} has {n}")
+        opt.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+        opt.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        steps = max(steps, int(float(st["step"])))
+    opt.steps, opt.lr = steps, float(groups[0]["lr"])
+
+
 def save_checkpoint(path, model, opt, scheduler=None, steps=0, epochs=0):
-    """the reference's checkpoint layout (trainers/base.py:91-111): {"model": state_dict, "optimizer", "scheduler",
-    "steps", "epochs"}.  "model" loads into the reference's / this package's `Serenade`; the optimizer entry holds the
-    two flat moment buffers with the parameter layout (name -> (offset, size)) they follow."""
+    """the reference's checkpoint file (trainers/base.py:91-111): {"model", "optimizer", "scheduler", "steps",
+    "epochs"} with "optimizer" / "scheduler" in the layout of `torch.optim.AdamW.state_dict()` /
+    `MultiStepLR.state_dict()`, so the reference's trainer resumes from it and vice versa."""
     import os
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save({"model": {k: v.cpu() for k, v in model.state_dict().items()},
-                "optimizer": {"m": opt.m.cpu(), "v": opt.v.cpu(), "steps": opt.steps, "lr": opt.lr, "betas": opt.betas,
-                              "eps": opt.eps, "weight_decay": opt.wd, "spans": dict(model.spans)},
+                "optimizer": _torch_adamw_state(model, opt),
                 "scheduler": None if scheduler is None else scheduler.state_dict(), "steps": int(steps),
                 "epochs": int(epochs)}, path)
 
 
 def load_checkpoint(path, model, opt=None, scheduler=None, load_only_params=False):
     """trainers/base.py:113-130: restores the weights (and BatchNorm statistics) in place; with an optimizer also its
-    moments and step count.  Returns (steps, epochs)."""
+    moments, step count and learning rate -- from a checkpoint of this package or of the reference's trainer (torch's
+    AdamW / MultiStepLR state_dicts).  Returns (steps, epochs)."""
     ck = torch.load(path, map_location="cpu")
     with torch.no_grad():
         for k, v in ck["model"].items():
@@ -948,13 +991,47 @@ def load_checkpoint(path, model, opt=None, scheduler=None, load_only_params=Fals
     if load_only_params or opt is None:
         return int(ck.get("steps", 0)), int(ck.get("epochs", 0))
     o = ck["optimizer"]
-    if dict(o["spans"]) != dict(model.spans):
-        raise ValueError("optimizer state was saved for a different parameter layout")
-    opt.m.copy_(o["m"]), opt.v.copy_(o["v"])
-    opt.steps, opt.lr = int(o["steps"]), float(o["lr"])
+    if "param_groups" in o and "state" in o:
+        with torch.no_grad():
+            _load_torch_adamw_state(o, model, opt)
+    elif "spans" in o:  # files written by round 2 of this package: flat moment buffers + their layout
+        if dict(o["spans"]) != dict(model.spans):
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        opt.m.copy_(o["m"]), opt.v.copy_(o["v"])
+        opt.steps, opt.lr = int(o["steps"]), float(o["lr"])
+    else:
+        raise ValueError(f"unrecognised optimizer entry (keys {sorted(o)}): expected torch.optim.AdamW.state_dict()")
     if scheduler is not None and ck.get("scheduler") is not None:
         scheduler.load_state_dict(ck["scheduler"])
     return int(ck["steps"]), int(ck["epochs"])
+
+
+def count_memset_nodes(graph):
+    """number of memset nodes in a captured `torch.cuda.CUDAGraph(keep_graph=True)` (hipGraphGetNodes /
+    hipGraphNodeGetType on its raw handle).
+
+    Why it matters (profiles/r3_graph_probe.json, tools/experiments/graph_probe.py): on this stack (ROCm 7.2, torch
+    2.10+rocm7.0) a hipMemsetAsync captured into a hipGraph fills with the right value on the FIRST replay and with
+    garbage from the second replay on, for every size and value tried.  torch's multi-block reductions zero their
+    semaphore buffer with exactly that call, so a captured `x.sum()` / `x.norm()` / `x.sum(0)` elects no last block
+    and returns stale numbers from replay 2 on (forty reductions in one capture: error 0 on replay 1, 3e17 after).
+    Kernels are unaffected.  Anything captured here must therefore hold no memset node."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    if hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    memsets = 0
+    for i in range(n.value):
+        kind = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(kind)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        memsets += kind.value == 2  # hipGraphNodeTypeMemset
+    return memsets, n.value
 
 
 class GraphedStep:
@@ -982,6 +1059,9 @@ class GraphedStep:
         # warm-up runs real steps (on the zero-filled static inputs): put weights, optimizer state and BatchNorm
         # statistics back afterwards, so constructing a GraphedStep leaves the training state untouched
         keep = (model.flat.clone(), opt.m.clone(), opt.v.clone(), opt.steps, {k: v.clone() for k, v in model.buffers.items()})
+        if warmup < 1:
+            raise ValueError("GraphedStep needs at least one warm-up step: workspaces, library handles and the autograd "
+                             "graph's accumulators must exist before the capture")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # library handles, workspaces and autotuning settle outside the capture
@@ -991,17 +1071,29 @@ class GraphedStep:
                 opt.step_captured()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.g1, self.g2 = torch.cuda.CUDAGraph(), None
+        self.g1, self.g2 = torch.cuda.CUDAGraph(keep_graph=True), None
         if self.split:
             with torch.cuda.graph(self.g1):
                 self._fwd_bwd()
-            self.g2 = torch.cuda.CUDAGraph()
+            self.g2 = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(self.g2, pool=self.g1.pool()):
                 opt.step_captured()
         else:
             with torch.cuda.graph(self.g1):
                 self._fwd_bwd()
                 opt.step_captured()
+        # a captured memset replays with a corrupted fill value on this stack (count_memset_nodes): a torch reduction
+        # that goes multi-block at this (B, L), or a library call that clears a flag buffer, would train on stale sums
+        # from the second step on -- refuse the bucket instead
+        self.nodes = 0
+        for g in (self.g1, self.g2):
+            if g is not None:
+                memsets, total = count_memset_nodes(g)
+                self.nodes += total
+                if memsets:
+                    raise RuntimeError(f"the captured step for B={B}, L={L} holds {memsets} memset node(s) of {total}: "
+                                       "hipGraph memset nodes replay wrongly on this ROCm stack (see "
+                                       "training.count_memset_nodes); run this bucket eagerly")
         model.flat.copy_(keep[0]), opt.m.copy_(keep[1]), opt.v.copy_(keep[2])
         opt.steps = keep[3]
         for k, v in keep[4].items():

@@ -263,12 +263,12 @@ def emul_call(name, a):
             for t in range(n):
                 dv[b * dst_bs + (off + t) * ld_dst + dc0: b * dst_bs + (off + t) * ld_dst + dc0 + C] = \
                     sv[b * src_bs + t * ld_src: b * src_bs + t * ld_src + C]
-    elif name == "srn_reflect_pad":
-        x, out, B, n, pad, ld = a
+    elif name == "srn_pad_signal":
+        x, out, B, n, pad, ld, mode = a
         xv = _v(x, B * n).reshape(B, n)
         ov = _v(out, B * ld).reshape(B, ld)
         ov[:] = 0
-        ov[:, :n + 2 * pad] = F.pad(xv.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        ov[:, :n + 2 * pad] = F.pad(xv.unsqueeze(1), (pad, pad), mode="constant" if mode else "reflect").squeeze(1)
     elif name == "srn_logmel":
         spec, mel_t, out, frames, nb, ld, n_mels, eps, mode = a
         sv = _v(spec, frames * ld).reshape(frames, ld)

@@ -204,3 +204,61 @@ def test_decode_cli_end_to_end_gpu(tmp_path):
 def test_cli_rejects_bad_argument_combinations(tmp_path):
     with pytest.raises(SystemExit):
         ssc_decode.main(["--outdir", str(tmp_path)])  # --stats / --checkpoint are required
+
+
+# ---- rank sharding of the decode loop: two gloo ranks, every conversion exactly once
+def _sharded_worker(rank, world, port, root, q):
+    import torch.distributed as dist
+    from pathlib import Path
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)  # two workers on the CI box's 8 cores
+    written = []
+    real = ssc_decode.write_wav_pcm16
+    ssc_decode.write_wav_pcm16 = lambda path, wave, sr: (written.append(os.path.basename(path)), real(path, wave, sr))[1]
+    root = Path(root)
+    argv = ["--dumpdir", str(root / "dump"), "--stats", str(root / "stats.joblib"), "--ref-dict", str(root / "refs.json"),
+            "--checkpoint", str(root / "exp" / "checkpoint.pkl"), "--verbose", "0", "--outdir", str(root / "out")]
+    with _emulator.installed():
+        torch.manual_seed(7)
+        ssc_decode.main(argv)
+        err = None
+        try:  # no --ref-dict under several ranks: every rank would draw its own prompts
+            ssc_decode.main([a for a in argv if a not in ("--ref-dict", str(root / "refs.json"))])
+        except ValueError as e:
+            err = str(e)
+    q.put((rank, written, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_decode_cli_shards_utterances_over_two_gloo_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    from tests.test_parallel_gloo import _free_port
+    _two_style_tree(tmp_path)
+    rng = np.random.default_rng(9)
+    for i in (3, 4, 5):  # 5 utterances over 2 ranks: 3 + 2
+        np.savez(tmp_path / "dump" / f"EN_spk1_song_Control_Group_000{i}.npz", **_feats(rng, 14 + i))
+    (tmp_path / "out").mkdir()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (w, e)) for r, w, e in (q.get() for _ in procs))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    utts = [f"EN_spk1_song_Control_Group_000{i}" for i in range(1, 6)]
+    conv = lambda names: sorted(n for n in names if not n.startswith("00_") and not n.endswith("_gt.wav"))
+    per_rank = {r: conv(w) for r, (w, _) in got.items()}
+    assert per_rank[0] == sorted(f"{u}_{s}.wav" for u in utts[:3] for s in ("Breathy", "Falsetto"))
+    assert per_rank[1] == sorted(f"{u}_{s}.wav" for u in utts[3:] for s in ("Breathy", "Falsetto"))
+    everything = got[0][0] + got[1][0]
+    assert len(everything) == len(set(everything))          # nothing written twice, by either rank
+    assert sorted(n for n in everything if n.startswith("00_")) == ["00_Breathy_reference.wav", "00_Falsetto_reference.wav"]
+    assert all(n in got[0][0] for n in ("00_Breathy_reference.wav", "00_Falsetto_reference.wav"))  # rank 0 only
+    files = sorted(os.listdir(tmp_path / "out"))
+    assert len(files) == 5 * (1 + 2 * 2) + 2
+    assert all("several ranks need --ref-dict" in e for _, e in got.values())

@@ -78,6 +78,7 @@ def _check(dev, n, B):
     mel = features.logmelfilterbank(x if B > 1 else x[0], SR, fft_size=FFT, hop_size=HOP, win_length=WIN, window="hann",
                                     num_mels=MELS, fmin=FMIN, fmax=FMAX)
     loud = features.loudness_extract(x if B > 1 else x[0], SR, HOP)
+    loud_r = features.loudness_extract(x if B > 1 else x[0], SR, HOP, pad_mode="reflect")
     frames = 1 + n // HOP
     assert mel.shape == ((B, frames, MELS) if B > 1 else (frames, MELS))
     assert loud.shape == ((B, frames) if B > 1 else (frames,))
@@ -87,6 +88,11 @@ def _check(dev, n, B):
                                   fmax=FMAX)
         assert np.abs(mel[b] - ref).max() < 2e-4  # log10 units; fp32 STFT + fp32 log
         assert np.abs(loud[b] - FO.loudness_extract(xs[b], SR, HOP)).max() < 2e-4
+        ref_r = FO.loudness_extract(xs[b], SR, HOP, pad_mode="reflect")  # librosa < 0.10's default for this call
+        assert np.abs(loud_r.reshape(B, frames).cpu().numpy()[b] - ref_r).max() < 2e-4
+        k = 2048 // 2 // HOP + 1  # only frames whose window reaches over an end see the padding
+        if frames > 2 * k:
+            assert np.abs(FO.loudness_extract(xs[b], SR, HOP)[k:-k] - ref_r[k:-k]).max() < 1e-12
     # natural log / base 2 variants and the default (win_length = fft_size, full band) go through the same code
     m2 = features.logmelfilterbank(x[0], SR, fft_size=FFT, hop_size=HOP, log_base=None)
     ref = FO.logmelfilterbank(xs[0], SR, fft_size=FFT, hop_size=HOP, log_base=None)

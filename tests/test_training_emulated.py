@@ -210,8 +210,34 @@ def test_checkpoint_resume_and_lr_schedule(tmp_path):
         for i in range(2, 4):
             fake_step(b, ob, sb, i)
     assert torch.equal(a.flat, b.flat) and torch.equal(oa.m, ob.m) and torch.equal(oa.v, ob.v) and ob.lr == 5e-4
-    ck = torch.load(str(tmp_path / "ck" / "checkpoint-2steps.pkl"))
+    ck = torch.load(str(tmp_path / "ck" / "checkpoint-2steps.pkl"), weights_only=False)
     assert set(ck) == {"model", "optimizer", "scheduler", "steps", "epochs"}
+    # the optimizer / scheduler entries are torch's own state_dicts: torch.optim.AdamW + MultiStepLR over parameters of
+    # the same shapes load them (what the reference's trainer does on --resume, trainers/base.py:113-130) and a
+    # checkpoint written by torch's objects loads here
+    ps = [torch.nn.Parameter(v.detach().clone()) for v in a.state_dict().values()]
+    topt = torch.optim.AdamW(ps, lr=1e-3, betas=oa.betas, eps=oa.eps, weight_decay=oa.wd)
+    tsch = torch.optim.lr_scheduler.MultiStepLR(topt, milestones=[3], gamma=0.5)
+    topt.load_state_dict(ck["optimizer"])
+    tsch.load_state_dict(ck["scheduler"])
+    k0 = next(iter(a.spans))
+    off, n = a.spans[k0]
+    assert topt.state[ps[0]]["exp_avg"].shape == ps[0].shape and float(topt.state[ps[0]]["step"]) == 2.0
+    assert tsch.last_epoch == 2 and topt.param_groups[0]["lr"] == 1e-3
+    torch.save({"model": ck["model"], "optimizer": topt.state_dict(), "scheduler": tsch.state_dict(), "steps": 2,
+                "epochs": 1}, str(tmp_path / "ck" / "from_torch.pkl"))
+    with _emulator.installed():
+        c = training.ParamStore(small, torch.device("cpu"), skip=[k for k in small if "running_" in k or "num_batches" in k])
+        c.buffers = {}
+        oc = training.AdamW(c, lr=9.0)
+        sc = training.MultiStepLR(oc, [7])
+        assert training.load_checkpoint(str(tmp_path / "ck" / "from_torch.pkl"), c, oc, sc) == (2, 1)
+        for i in range(2, 4):
+            fake_step(c, oc, sc, i)
+    assert torch.equal(a.flat, c.flat) and torch.equal(oa.m, oc.m) and oc.lr == 5e-4
+    with pytest.raises(ValueError):
+        torch.save({**ck, "optimizer": {"something": 1}}, str(tmp_path / "ck" / "bad.pkl"))
+        training.load_checkpoint(str(tmp_path / "ck" / "bad.pkl"), c, oc)
 
 
 def test_overwrite_gradient_path_equals_accumulation():
