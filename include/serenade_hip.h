@@ -401,6 +401,35 @@ typedef struct SrnExcitationParams {
 } SrnExcitationParams;
 int srn_sifigan_excitation(const SrnExcitationParams* p, void* stream);
 
+/*
+ * Contractions over TIME of the training step (what `loss.backward()` of trainers/ssc.py:57-96 runs for the
+ * Conv1d / Linear weights of matcha_components/decoder.py and for diffusers' attention), exact fp32 MFMA:
+ *
+ *   out[z, m, j * N + n] = alpha * sum_{item, t} a[z, item, t, m] * b[z, item, t * stride + shift[j], n]
+ *
+ * with rows of b outside [0, T_b) read as zero.  z = zb * n_head + zh walks independent problems.
+ *   weight gradient of a conv:  a = dY (B items of T_out rows, M = C_out), b = X (T_in rows, N = C_in), shift = taps
+ *                               -> dW in the packed layout (C_out, taps * C_in) srn_conv_gemm reads;
+ *   attention:  dV = P^T dO and dK = dS^T Q, one problem per (batch, head), n_items = 1, T_a = T_b = L.
+ * Operands are used as they lie in memory (time-major): no transposes, no padded copies.  When the output has too
+ * few tiles to fill the chip the time axis is sliced over extra workgroups; the slices go through `ws`
+ * (srn_tn_gemm_workspace_bytes) and are added in slice order: results are bit-reproducible.
+ */
+typedef struct SrnTnGemmParams {
+  int32_t n_batch, n_head;   /* problems */
+  int32_t n_items, T_a, T_b; /* contraction: items x T_a rows of a, paired with rows of b in [0, T_b) */
+  int32_t stride, n_shifts;
+  int32_t shift[SRN_MAX_TAPS];
+  int32_t M, N;              /* N % 4 == 0; M free with lda >= roundup(M, 4) */
+  const float* a; int64_t a_bs, a_hs, a_is; int32_t lda;
+  const float* b; int64_t b_bs, b_hs, b_is; int32_t ldb;
+  float* out; int64_t out_bs, out_hs; int32_t ldc;  /* ldc >= n_shifts * N */
+  float alpha;
+  float* ws; int64_t ws_bytes;  /* or NULL: no slicing */
+} SrnTnGemmParams;
+int srn_tn_gemm(const SrnTnGemmParams* p, void* stream);
+int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p);
+
 #ifdef __cplusplus
 }
 #endif

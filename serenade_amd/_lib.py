@@ -68,6 +68,17 @@ class SrnWorldParams(ctypes.Structure):
     ]
 
 
+class SrnTnGemmParams(ctypes.Structure):
+    _fields_ = [
+        ("n_batch", c_int32), ("n_head", c_int32), ("n_items", c_int32), ("T_a", c_int32), ("T_b", c_int32),
+        ("stride", c_int32), ("n_shifts", c_int32), ("shift", c_int32 * SRN_MAX_TAPS), ("M", c_int32), ("N", c_int32),
+        ("a", c_void_p), ("a_bs", c_int64), ("a_hs", c_int64), ("a_is", c_int64), ("lda", c_int32),
+        ("b", c_void_p), ("b_bs", c_int64), ("b_hs", c_int64), ("b_is", c_int64), ("ldb", c_int32),
+        ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ldc", c_int32),
+        ("alpha", c_float), ("ws", c_void_p), ("ws_bytes", c_int64),
+    ]
+
+
 class SrnExcitationParams(ctypes.Structure):
     _fields_ = [
         ("n_batch", c_int32), ("max_frames", c_int32), ("fs", c_int32), ("hop", c_int32),
@@ -122,6 +133,8 @@ _SIGS = {
     "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "srn_multi_copy": (c_int, [POINTER(SrnCopyList), _P, _P]),
     "srn_sumsq_blocks": (c_int, [c_int64]),
+    "srn_tn_gemm": (c_int, [POINTER(SrnTnGemmParams), _P]),
+    "srn_tn_gemm_workspace_bytes": (c_int64, [POINTER(SrnTnGemmParams)]),
     "srn_world_cheaptrick": (c_int, [POINTER(SrnWorldParams), _P]),
     "srn_world_d4c": (c_int, [POINTER(SrnWorldParams), _P]),
     "srn_world_project": (c_int, [_P, c_int64, c_int, c_int, _P, c_int, c_int, _P, c_int, _P]),

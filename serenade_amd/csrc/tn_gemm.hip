@@ -1,0 +1,223 @@
+// tn_gemm.hip -- contractions over TIME for the training step: weight gradients of every conv / linear
+// (dW_j = sum_{b,t} dY[b,t,:]^T X[b, t*stride + o_j, :]) and the two attention gradients that contract over query
+// rows (dV = P^T dO, dK = dS^T Q), exact fp32 on v_mfma_f32_32x32x2_f32.  Reference: what autograd does for
+// serenade/models/matcha_components/decoder.py's Conv1d / Linear layers and diffusers' attention under
+// trainers/ssc.py:57-96 (loss.backward()).
+//
+// Both operands are TIME-MAJOR in HBM (row = a time step, channels contiguous), which is exactly the MFMA's fragment
+// order once a k-slab sits in LDS as [k][m]: lane (m = lane % 32, k = lane / 32) reads consecutive floats of one row
+// per 32-lane group (conflict-free ds_read_b32, no transpose anywhere).  So a block streams 16-row slabs of A and of
+// the tap-shifted B (rows outside the item read as zero: "same" padding without guard rows or padded copies) through
+// a double-buffered LDS stage with coalesced 16-B global loads, and multiplies them as they are.
+//
+// The output (M x N per tap) is small and the contraction long (batch x time), so the time axis is sliced over
+// `ksplit` workgroup sets writing raw partial tiles to a workspace; srn_tn_gemm's reduce kernel adds the slices IN
+// SLICE ORDER (bit-reproducible, no atomics) and scales.  Attention gradients (one problem per batch x head, K = L)
+// fill the chip without slicing and store directly.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "conv_common.h"
+#include "serenade_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int PITCH = BM + 4;  // floats per k-row of a slab (16-B aligned rows, banks rotate by 4 per row)
+constexpr int SLAB = BK * PITCH;
+constexpr int MAX_SPLIT = 32;
+
+__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p, const int m_tiles, const int n_tiles,
+                                                          const int ksplit, const int k_per) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][SLAB];  // [stage][A | B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // grid: x = tile (m fastest) of one (problem, tap), y = tap, z = problem * ksplit + slice
+  const int mt = blockIdx.x % m_tiles, nt = blockIdx.x / m_tiles;
+  const int tap = blockIdx.y;
+  const int z = blockIdx.z / ksplit, slice = blockIdx.z - z * ksplit;
+  const int zb = z / p.n_head, zh = z - zb * p.n_head;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int shift = p.shift[tap];
+  const float* A = p.a + (int64_t)zb * p.a_bs + (int64_t)zh * p.a_hs;
+  const float* Bm = p.b + (int64_t)zb * p.b_bs + (int64_t)zh * p.b_hs;
+  const int K = p.n_items * p.T_a;  // contraction index r = item * T_a + t
+  const int k_begin = slice * k_per, k_end = min(K, k_begin + k_per);
+
+  // global -> register -> LDS: per step each operand is 16 rows x 128 floats = 512 float4: two per thread
+  const int lrow = tid >> 5;        // 0..7 (+8)
+  const int lcol = (tid & 31) * 4;  // float offset in the 128-wide slab row
+  float4 ra[2], rb[2];
+  auto load = [&](const int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = k0 + lrow + 8 * i;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (r < k_end) {
+        const int item = r / p.T_a, t = r - item * p.T_a;
+        if (m0 + lcol < p.M) va = *reinterpret_cast<const float4*>(A + (int64_t)item * p.a_is + (int64_t)t * p.lda + m0 + lcol);
+        const int tb = t * p.stride + shift;
+        if (tb >= 0 && tb < p.T_b && n0 + lcol < p.N)
+          vb = *reinterpret_cast<const float4*>(Bm + (int64_t)item * p.b_is + (int64_t)tb * p.ldb + n0 + lcol);
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto store = [&](const int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&lds[st][0][(lrow + 8 * i) * PITCH + lcol]) = ra[i];
+      *reinterpret_cast<float4*>(&lds[st][1][(lrow + 8 * i) * PITCH + lcol]) = rb[i];
+    }
+  };
+
+  // wave tile 64 x 64: waves 2 (m) x 2 (n)
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int fm = lane & 31, fk = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int n_steps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
+  if (n_steps > 0) {
+    load(k_begin);
+    store(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < n_steps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < n_steps) load(k_begin + (s + 1) * BK);
+    const float* la = &lds[cur][0][0];
+    const float* lb = &lds[cur][1][0];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int row = (kk + fk) * PITCH;
+      const float a0 = la[row + wm0 + fm], a1 = la[row + wm0 + 32 + fm];
+      const float b0 = lb[row + wn0 + fm], b1 = lb[row + wn0 + 32 + fm];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (s + 1 < n_steps) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  float* out;
+  int64_t ld;
+  float alpha = 1.f;
+  if (ksplit > 1) {
+    ld = (int64_t)p.n_shifts * p.N;
+    out = p.ws + (((int64_t)slice * p.n_batch * p.n_head + z) * p.M) * ld + (int64_t)tap * p.N;
+  } else {
+    ld = p.ldc;
+    out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs + (int64_t)tap * p.N;
+    alpha = p.alpha;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn0 + 32 * j + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.M) out[(int64_t)row * ld + col] = acc[i][j][e] * alpha;
+      }
+    }
+}
+
+// out[z][m][:] = alpha * sum_s ws[s][z][m][:], slices in order; one float4 per thread
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p, const int ksplit) {
+  const int64_t cols = (int64_t)p.n_shifts * p.N;  // % 4 == 0
+  const int64_t per_z = (int64_t)p.M * cols;
+  const int64_t Z = (int64_t)p.n_batch * p.n_head;
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= Z * per_z) return;
+  const int64_t z = i4 / per_z, rem = i4 - z * per_z;
+  const int64_t m = rem / cols, c = rem - m * cols;
+  const float* w = p.ws + i4;
+  float4 v = *reinterpret_cast<const float4*>(w);
+  for (int s = 1; s < ksplit; ++s) {
+    const float4 q = *reinterpret_cast<const float4*>(w + (int64_t)s * Z * per_z);
+    v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+  }
+  const int zb = (int)(z / p.n_head), zh = (int)(z - (int64_t)zb * p.n_head);
+  float* o = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs + m * p.ldc + c;
+  *reinterpret_cast<float4*>(o) = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
+}
+
+int plan_split(const SrnTnGemmParams& p, int& k_per) {
+  const int64_t K = (int64_t)p.n_items * p.T_a;
+  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.n_shifts * p.n_batch * p.n_head;
+  int ks = 1;
+  if (tiles < 384) {  // ~3 workgroups per CU wanted; never fewer than 8 slabs per slice
+    ks = (int)((768 + tiles - 1) / tiles);
+    const int64_t cap = K / (8 * BK);
+    if (ks > cap) ks = (int)cap;
+    if (ks > MAX_SPLIT) ks = MAX_SPLIT;
+    if (ks < 1) ks = 1;
+  }
+  k_per = (int)(((K + ks - 1) / ks + BK - 1) / BK * BK);
+  ks = (int)((K + k_per - 1) / k_per);  // no empty slice
+  return ks < 1 ? 1 : ks;
+}
+
+}  // namespace
+
+extern "C" int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p) {
+  if (p == nullptr || p->M <= 0 || p->N <= 0 || p->n_items <= 0 || p->T_a <= 0 || p->n_shifts <= 0) return 0;
+  int k_per = 0;
+  const int ks = plan_split(*p, k_per);
+  if (ks <= 1) return 0;
+  return (int64_t)ks * p->n_batch * p->n_head * p->M * p->n_shifts * p->N * (int64_t)sizeof(float);
+}
+
+extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
+  SRN_CHECK_ARG(pp != nullptr, "tn_gemm: null params");
+  const SrnTnGemmParams& p = *pp;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  SRN_CHECK_ARG(p.a && p.b && p.out, "tn_gemm: null a / b / out");
+  SRN_CHECK_ARG(p.n_batch > 0 && p.n_head > 0 && p.n_items > 0 && p.T_a > 0 && p.T_b > 0 && p.M > 0 && p.N > 0,
+                "tn_gemm: bad sizes");
+  SRN_CHECK_ARG(p.n_shifts >= 1 && p.n_shifts <= SRN_MAX_TAPS && p.stride >= 1, "tn_gemm: n_shifts %d / stride %d",
+                p.n_shifts, p.stride);
+  // M may be ragged (attention: M = L): a's rows are read in 16-byte pieces up to roundup(M, 4) <= lda, and whatever
+  // sits in those pad columns only reaches output rows >= M, which are not stored
+  SRN_CHECK_ARG(p.N % 4 == 0 && p.lda % 4 == 0 && p.lda >= (p.M + 3) / 4 * 4 && p.ldb % 4 == 0 && p.ldc % 4 == 0 &&
+                    p.a_bs % 4 == 0 && p.a_hs % 4 == 0 && p.a_is % 4 == 0 && p.b_bs % 4 == 0 && p.b_hs % 4 == 0 &&
+                    p.b_is % 4 == 0 && p.out_bs % 4 == 0 && p.out_hs % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b) |
+                      reinterpret_cast<uintptr_t>(p.out)) & 15) == 0,
+                "tn_gemm: N, leading dimensions and strides must be multiples of 4 floats (lda >= roundup(M, 4)), pointers "
+                "16-byte aligned");
+  SRN_CHECK_ARG(p.ldc >= p.n_shifts * p.N, "tn_gemm: ldc %d < n_shifts * N", p.ldc);
+  SRN_CHECK_ARG((int64_t)p.n_items * p.T_a < (1ll << 31), "tn_gemm: contraction too long");
+  int k_per = 0;
+  int ks = plan_split(p, k_per);
+  if (ks > 1) {
+    const int64_t need = (int64_t)ks * p.n_batch * p.n_head * p.M * p.n_shifts * p.N * (int64_t)sizeof(float);
+    if (p.ws == nullptr || p.ws_bytes < need || (reinterpret_cast<uintptr_t>(p.ws) & 15) != 0) {
+      ks = 1;  // no (or too small a) workspace: correct, just fewer workgroups
+      k_per = (int)(((int64_t)p.n_items * p.T_a + BK - 1) / BK * BK);
+    }
+  }
+  const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
+  const int64_t gz = (int64_t)p.n_batch * p.n_head * ks;
+  SRN_CHECK_ARG(gz <= 65535 && (int64_t)m_tiles * n_tiles < (1ll << 31), "tn_gemm: grid too large");
+  hipLaunchKernelGGL(tn_gemm_kernel, dim3(m_tiles * n_tiles, p.n_shifts, (unsigned)gz), dim3(256), 0, stream, p,
+                     m_tiles, n_tiles, ks, k_per);
+  if (ks > 1) {
+    const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, ks);
+  }
+  SRN_CHECK_LAUNCH();
+  return 0;
+}

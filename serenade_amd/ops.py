@@ -187,6 +187,50 @@ class MultiCopyOp:
             check(self._fn(ctypes.byref(lst), _ptr(self.dst), st), "srn_multi_copy")
 
 
+_TN_WS = {}
+
+
+def tn_workspace(device, nbytes):
+    """slices of a time-sliced srn_tn_gemm: per (device, stream) like the split-K slab, grown on demand"""
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (str(device), stream)
+    if key not in _TN_WS or _TN_WS[key].numel() < nbytes:
+        _TN_WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    return _TN_WS[key]
+
+
+class TnGemmOp:
+    """srn_tn_gemm (include/serenade_hip.h): out[z, m, j*N + n] = alpha * sum_{item,t} a[z,item,t,m] *
+    b[z,item,t*stride + shifts[j], n].  a / b / out: tensor or (tensor, element offset)."""
+
+    __slots__ = ("p", "kw", "_fn", "_ws")
+
+    def __init__(self, *, a, b, out, n_items, T_a, T_b, M, N, lda, ldb, ldc, shifts=(0,), stride=1, n_batch=1,
+                 n_head=1, a_bs=0, a_hs=0, a_is=0, b_bs=0, b_hs=0, b_is=0, out_bs=0, out_hs=0, alpha=1.0):
+        self.kw = dict(a=a, b=b, out=out, n_items=n_items, T_a=T_a, T_b=T_b, M=M, N=N, lda=lda, ldb=ldb, ldc=ldc,
+                       shifts=tuple(int(v) for v in shifts), stride=stride, n_batch=n_batch, n_head=n_head, a_bs=a_bs,
+                       a_hs=a_hs, a_is=a_is, b_bs=b_bs, b_hs=b_hs, b_is=b_is, out_bs=out_bs, out_hs=out_hs, alpha=alpha)
+        p = _lib.SrnTnGemmParams()
+        p.n_batch, p.n_head, p.n_items, p.T_a, p.T_b = n_batch, n_head, n_items, T_a, T_b
+        p.stride, p.n_shifts, p.M, p.N = stride, len(shifts), M, N
+        for i, v in enumerate(shifts):
+            p.shift[i] = int(v)
+        p.a, p.a_bs, p.a_hs, p.a_is, p.lda = _ptr(a), a_bs, a_hs, a_is, lda
+        p.b, p.b_bs, p.b_hs, p.b_is, p.ldb = _ptr(b), b_bs, b_hs, b_is, ldb
+        p.out, p.out_bs, p.out_hs, p.ldc, p.alpha = _ptr(out), out_bs, out_hs, ldc, float(alpha)
+        self._fn = _lib.lib().srn_tn_gemm
+        need = int(_lib.lib().srn_tn_gemm_workspace_bytes(ctypes.byref(p)))
+        self._ws = None
+        if need:
+            o = out[0] if isinstance(out, tuple) else out
+            self._ws = tn_workspace(o.device, need)
+            p.ws, p.ws_bytes = self._ws.data_ptr(), self._ws.numel()
+        self.p = p
+
+    def __call__(self, stream=None):
+        check(self._fn(ctypes.byref(self.p), stream if stream is not None else _stream()), "srn_tn_gemm")
+
+
 _WPLANES = {}  # (data_ptr, version, shape, ...) -> (planes, weight) bf16 weight planes, split once per weight VALUE
 
 

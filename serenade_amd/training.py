@@ -29,7 +29,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .ops import ConvOp
+from .ops import TnGemmOp, ConvOp
 
 __all__ = ["Estimator", "TrainSerenade", "ParamStore", "GraphedStep", "MultiStepLR", "save_checkpoint", "load_checkpoint", "GradSync", "AdamW", "cfm_loss", "conv1d", "gn_mish", "row_ln", "attention_core", "geglu"]
 
@@ -110,25 +110,12 @@ class _Conv(torch.autograd.Function):
                     _launch_conv(dy, wsel, None, dx, [(ph - taps[j]) // stride for j in sel], B, T_out, rows, N, C,
                                  out_t_stride=stride, out_t_off=ph, ld_out=C, out_bs=T * C)
         if ctx.needs_input_grad[1]:
-            # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- contraction over time: rocBLAS.
-            # Stride 1: one transposed-A GEMM per tap over the batch-flattened rows; both operands carry P zero rows
-            # between batch items, so a tap's shift never pairs rows of different items.
-            if stride == 1 and T_out == T:
-                P = max(abs(o) for o in taps)
-                xp = F.pad(x, (0, 0, P, P)).reshape(-1, C) if P else x.reshape(-1, C)
-                dyp = F.pad(dy, (0, 0, P, P)).reshape(-1, N) if P else dy.reshape(-1, N)
-                n = xp.shape[0]
-                mats = [torch.matmul(dyp[P:n - P].t(), xp[P + o:n - P + o]) for o in taps]
-            else:
-                lo, hi = min(min(taps), 0), max(max(taps), 0)
-                need = (T_out - 1) * stride + hi + 1
-                xp = F.pad(x, (0, 0, -lo, max(0, need - T)))
-                dyt = dy.transpose(1, 2)  # (B, N, T_out)
-                mats = []
-                for o in taps:
-                    xs = xp[:, o - lo: o - lo + (T_out - 1) * stride + 1: stride]  # (B, T_out, C) view
-                    mats.append(torch.matmul(dyt, xs).sum(0))  # (N, C)
-            dw = torch.stack(mats, dim=1).reshape(N, nt * C) if nt > 1 else mats[0]
+            # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- a contraction over time on operands
+            # that are time-major as they lie: srn_tn_gemm (rows outside the item read as zero; time sliced over
+            # workgroups, slices added in order), straight into the packed (N, taps * C) layout
+            dw = torch.empty(N, nt * C, device=dy.device, dtype=torch.float32)
+            TnGemmOp(a=dy, b=x, out=dw, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=nt * C, shifts=taps,
+                     stride=stride, a_is=T_out * N, b_is=T * C)()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.reshape(-1, N))  # own kernel, not a torch reduction: see AdamW._grad_norm
         return dx, dw, db, None, None, None, None
@@ -324,13 +311,13 @@ class _AttnCore(torch.autograd.Function):
         ConvOp(in0=dS, w=kt, out=dqkv, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
                in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * three, out_hs=hd,
                ld_out=three, precision=_lib.PREC_FP32)()
-        # dK = dS^T Q, dV = P^T dO: contraction over query rows (transposed-A GEMMs): rocBLAS
-        q = qkv[:, :, :inner].view(B, L, H, hd).permute(0, 2, 1, 3)
-        doh = do.view(B, L, H, hd).permute(0, 2, 1, 3)
-        dk = torch.matmul(dS[..., :L].transpose(-1, -2), q)  # (B, H, L, hd)
-        dv = torch.matmul(P[..., :L].transpose(-1, -2), doh)
-        dqkv[:, :, inner:2 * inner] = dk.permute(0, 2, 1, 3).reshape(B, L, inner)
-        dqkv[:, :, 2 * inner:] = dv.permute(0, 2, 1, 3).reshape(B, L, inner)
+        # dK = dS^T Q, dV = P^T dO: contractions over query rows, one problem per (batch, head): srn_tn_gemm reads dS / P
+        # (keys contiguous) and Q / dO (channels contiguous) as they lie and writes the head's slice of dqkv
+        for src, rhs, col in ((dS, (qkv, 0), inner), (P, do, 2 * inner)):
+            TnGemmOp(a=src, b=rhs, out=(dqkv, col), n_items=1, T_a=L, T_b=L, M=L, N=hd, lda=Lp,
+                     ldb=(three if isinstance(rhs, tuple) else inner), ldc=three, n_batch=B, n_head=H,
+                     a_bs=H * L * Lp, a_hs=L * Lp, b_bs=L * (three if isinstance(rhs, tuple) else inner), b_hs=hd,
+                     out_bs=L * three, out_hs=hd)()
         return dqkv, None, None
 
 

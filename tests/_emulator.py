@@ -432,6 +432,29 @@ def emul_resunit(kw):
     _v(g("out"), B * T * C).reshape(B, T, C)[:] = y
 
 
+def emul_tn_gemm(kw):
+    """executable spec of srn_tn_gemm"""
+    g = kw.get
+    a, oa = _flat(g("a"))
+    b, ob = _flat(g("b"))
+    out, oo = _flat(g("out"))
+    M, N, T_a, T_b, stride = g("M"), g("N"), g("T_a"), g("T_b"), g("stride")
+    for zb in range(g("n_batch")):
+        for zh in range(g("n_head")):
+            for j, sh in enumerate(g("shifts")):
+                acc = torch.zeros(M, N, dtype=torch.float64)
+                for it in range(g("n_items")):
+                    a0 = oa + zb * g("a_bs") + zh * g("a_hs") + it * g("a_is")
+                    b0 = ob + zb * g("b_bs") + zh * g("b_hs") + it * g("b_is")
+                    am = torch.as_strided(a, (T_a, M), (g("lda"), 1), a0).double()
+                    tb = torch.arange(T_a) * stride + sh
+                    ok = (tb >= 0) & (tb < T_b)
+                    rows = torch.as_strided(b, (T_b, N), (g("ldb"), 1), b0).double()[tb.clamp(0, T_b - 1)]
+                    acc += am.t() @ (rows * ok[:, None])
+                o0 = oo + zb * g("out_bs") + zh * g("out_hs") + j * N
+                torch.as_strided(out, (M, N), (g("ldc"), 1), o0).copy_((acc * g("alpha")).float())
+
+
 def emul_multi_copy(self_, stream=None):
     flat = self_.dst.view(-1)
     for t, o in zip(self_.srcs, self_.offs):
@@ -448,6 +471,16 @@ class installed:
                        ops.ResUnitOp.__call__)
         self._saved_mc = ops.MultiCopyOp.__call__
         ops.MultiCopyOp.__call__ = emul_multi_copy
+        self._saved_tn = (ops.TnGemmOp.__call__, ops.TnGemmOp.__init__)
+        ops.TnGemmOp.__call__ = lambda self_, stream=None: emul_tn_gemm(self_.kw)
+
+        def tn_init(self_, **kw):  # no library call (workspace query) on the CPU
+            kw.setdefault("shifts", (0,))
+            for k, v in dict(stride=1, n_batch=1, n_head=1, a_bs=0, a_hs=0, a_is=0, b_bs=0, b_hs=0, b_is=0, out_bs=0,
+                             out_hs=0, alpha=1.0).items():
+                kw.setdefault(k, v)
+            self_.kw = kw
+        ops.TnGemmOp.__init__ = tn_init
         ops.ConvOp.__call__ = lambda self_, stream=None: emul_conv(self_.kw)
         ops.ResUnitOp.__call__ = lambda self_, stream=None: emul_resunit(self_.kw)
         ops.CallOp.__call__ = lambda self_, stream=None: emul_call(self_.name, self_.targs)
@@ -458,5 +491,6 @@ class installed:
     def __exit__(self, *exc):
         ops.ConvOp.__call__, ops.CallOp.__call__, guards, ops.ResUnitOp.__call__ = self._saved
         ops.MultiCopyOp.__call__ = self._saved_mc
+        ops.TnGemmOp.__call__, ops.TnGemmOp.__init__ = self._saved_tn
         for m, g in zip(self._mods, guards):
             m._require_cuda = g

@@ -394,3 +394,48 @@ def test_memset_guard_sees_torch_reductions_and_clears_the_product_step(dev):
     assert step.nodes > 500 and training.count_memset_nodes(step.g1)[0] == 0
     with pytest.raises(ValueError):
         training.GraphedStep(model, training.AdamW(model), 2, 256, warmup=0)
+
+
+# ---- srn_tn_gemm: contractions over time (weight gradients, dK, dV) against fp64 torch
+@pytest.mark.parametrize("case", ["wgrad_k3", "wgrad_stride2", "wgrad_valid", "wgrad_tiny_k", "attn", "ragged_m"])
+def test_tn_gemm_against_fp64(dev, case):
+    from serenade_amd.ops import TnGemmOp
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    if case.startswith("wgrad"):
+        B, T, C, N, taps, stride, T_out = {"wgrad_k3": (4, 515, 256, 512, (-1, 0, 1), 1, 515),
+                                           "wgrad_stride2": (3, 301, 128, 96, (-1, 0, 1), 2, 151),
+                                           "wgrad_valid": (2, 70, 64, 80, (0, 2, 4, 6), 1, 64),
+                                           "wgrad_tiny_k": (3, 1, 2048, 512, (0,), 1, 1)}[case]
+        x, dy = r(B, T, C), r(B, T_out, N)
+        dw = torch.full((N, len(taps) * C), float("nan"), device=dev)
+        TnGemmOp(a=dy, b=x, out=dw, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C, shifts=taps,
+                 stride=stride, a_is=T_out * N, b_is=T * C)()
+        ref = torch.zeros(N, len(taps), C, dtype=torch.float64)
+        xd, dyd = x.double().cpu(), dy.double().cpu()
+        for j, o in enumerate(taps):
+            for t in range(T_out):
+                tb = t * stride + o
+                if 0 <= tb < T:
+                    ref[:, j] += torch.einsum("bn,bc->nc", dyd[:, t], xd[:, tb])
+        got = dw.cpu().double().view(N, len(taps), C)
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max() < 2e-5 * ref.abs().max(), case
+        # bit-reproducible (slices are added in order)
+        dw2 = torch.empty_like(dw)
+        TnGemmOp(a=dy, b=x, out=dw2, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C,
+                 shifts=taps, stride=stride, a_is=T_out * N, b_is=T * C)()
+        assert torch.equal(dw, dw2)
+    else:
+        B, H, L, hd = (2, 4, 256, 64) if case == "attn" else (2, 2, 203, 32)
+        Lp = (L + 31) // 32 * 32
+        P = r(B, H, L, Lp)
+        do = r(B, L, H * hd)
+        out = torch.zeros(B, L, 3 * H * hd, device=dev)
+        TnGemmOp(a=P, b=do, out=(out, 2 * H * hd), n_items=1, T_a=L, T_b=L, M=L, N=hd, lda=Lp, ldb=H * hd, ldc=3 * H * hd,
+                 n_batch=B, n_head=H, a_bs=H * L * Lp, a_hs=L * Lp, b_bs=L * H * hd, b_hs=hd, out_bs=L * 3 * H * hd,
+                 out_hs=hd, alpha=0.5)()
+        ref = 0.5 * torch.einsum("bhij,bihd->bjhd", P[..., :L].double().cpu(), do.double().cpu().view(B, L, H, hd))
+        got = out.cpu().double()[:, :, 2 * H * hd:].view(B, L, H, hd)
+        assert (got - ref).abs().max() < 2e-5 * ref.abs().max()
+        assert not out[:, :, :2 * H * hd].any()  # nothing outside the head slices was touched
