@@ -426,9 +426,39 @@ typedef struct SrnTnGemmParams {
   float* out; int64_t out_bs, out_hs; int32_t ldc;  /* ldc >= n_shifts * N */
   float alpha;
   float* ws; int64_t ws_bytes;  /* or NULL: no slicing */
+  int32_t n_inner;              /* > 1: item i = (i / n_inner, i % n_inner) with strides (x_is, x_is2) -- conv2d's */
+  int64_t a_is2, b_is2;         /* (batch, output row) items; 0 / 1: one level */
 } SrnTnGemmParams;
 int srn_tn_gemm(const SrnTnGemmParams* p, void* stream);
 int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p);
+
+/*
+ * Training-mode pieces of the GST style encoder (serenade/modules/gst/style_encoder.py:171-191,235-252 under autograd;
+ * SURVEY 8 f4).  Channels-last rows throughout.
+ */
+/* BatchNorm2d(training) + ReLU over `rows` x C: stats (2, C) = (batch mean, 1 / sqrt(biased var + eps)) kept for the
+ * backward; running statistics updated like nn.BatchNorm2d (momentum, unbiased variance) when given.
+ * partial: srn_bn_chunks(rows) * 2 * C floats of scratch.  C % 4 == 0. */
+int srn_bn_chunks(int64_t rows);
+int srn_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                    float* partial, float* stats, float* y, int64_t rows, int C, float eps, float momentum, void* stream);
+/* dx, and sums (2, C) = (dbeta, dgamma). */
+int srn_bn_relu_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma,
+                    float* partial, float* sums, float* dx, int64_t rows, int C, void* stream);
+/* nn.GRU recurrence (gate order r, z, n) on gi = x W_ih^T + b_ih (B, T, 3H), zero initial state: hs (B, T+1, H) all
+ * hidden states, gates (B, T, 4H) = [r | z | n | W_hn h + b_hn].  w_hh_t = W_hh transposed (H, 3H). */
+int srn_gru_train_fwd(const float* gi, const float* w_hh_t, const float* b_hh, float* hs, float* gates, int B, int T,
+                      int H, void* stream);
+/* BPTT from dh_last (B, H): dgi, dgh (B, T, 3H); dW_hh = dgh^T hs[:, :T], db_hh = sum dgh are srn_tn_gemm / srn_colsum. */
+int srn_gru_train_bwd(const float* dh_last, const float* w_hh, const float* hs, const float* gates, float* dgi,
+                      float* dgh, int B, int T, int H, void* stream);
+/* StyleTokenLayer's attention core: one query row q (B, F) per item over keys / values (n_tok, F), n_head heads:
+ * p (B, n_head, n_tok) softmax weights, ctx (B, F). */
+int srn_token_attn_fwd(const float* q, const float* k, const float* v, float* p, float* ctx, int B, int n_tok, int F,
+                       int n_head, void* stream);
+/* dq (B, F); dk_part, dv_part (B, n_tok, F): per-item terms, summed over items by the caller (srn_colsum). */
+int srn_token_attn_bwd(const float* dctx, const float* q, const float* k, const float* v, const float* p, float* dq,
+                       float* dk_part, float* dv_part, int B, int n_tok, int F, int n_head, void* stream);
 
 #ifdef __cplusplus
 }

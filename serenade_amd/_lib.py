@@ -76,6 +76,7 @@ class SrnTnGemmParams(ctypes.Structure):
         ("b", c_void_p), ("b_bs", c_int64), ("b_hs", c_int64), ("b_is", c_int64), ("ldb", c_int32),
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ldc", c_int32),
         ("alpha", c_float), ("ws", c_void_p), ("ws_bytes", c_int64),
+        ("n_inner", c_int32), ("a_is2", c_int64), ("b_is2", c_int64),
     ]
 
 
@@ -133,6 +134,13 @@ _SIGS = {
     "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "srn_multi_copy": (c_int, [POINTER(SrnCopyList), _P, _P]),
     "srn_sumsq_blocks": (c_int, [c_int64]),
+    "srn_bn_chunks": (c_int, [c_int64]),
+    "srn_bn_relu_fwd": (c_int, [_P] * 8 + [c_int64, c_int, c_float, c_float, _P]),
+    "srn_bn_relu_bwd": (c_int, [_P] * 8 + [c_int64, c_int, _P]),
+    "srn_gru_train_fwd": (c_int, [_P] * 5 + [c_int] * 3 + [_P]),
+    "srn_gru_train_bwd": (c_int, [_P] * 6 + [c_int] * 3 + [_P]),
+    "srn_token_attn_fwd": (c_int, [_P] * 5 + [c_int] * 4 + [_P]),
+    "srn_token_attn_bwd": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
     "srn_tn_gemm": (c_int, [POINTER(SrnTnGemmParams), _P]),
     "srn_tn_gemm_workspace_bytes": (c_int64, [POINTER(SrnTnGemmParams)]),
     "srn_world_cheaptrick": (c_int, [POINTER(SrnWorldParams), _P]),

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
   const float* Bm = p.b + (int64_t)zb * p.b_bs + (int64_t)zh * p.b_hs;
   const int K = p.n_items * p.T_a;  // contraction index r = item * T_a + t
   const int k_begin = slice * k_per, k_end = min(K, k_begin + k_per);
+  const int n_inner = p.n_inner > 1 ? p.n_inner : 1;
 
   // global -> register -> LDS: per step each operand is 16 rows x 128 floats = 512 float4: two per thread
   const int lrow = tid >> 5;        // 0..7 (+8)
@@ -55,10 +56,14 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
       if (r < k_end) {
         const int item = r / p.T_a, t = r - item * p.T_a;
-        if (m0 + lcol < p.M) va = *reinterpret_cast<const float4*>(A + (int64_t)item * p.a_is + (int64_t)t * p.lda + m0 + lcol);
+        const int i1 = item / n_inner, i2 = item - i1 * n_inner;  // items may be a 2-level grid (conv2d: batch x row)
+        if (m0 + lcol < p.M)
+          va = *reinterpret_cast<const float4*>(A + (int64_t)i1 * p.a_is + (int64_t)i2 * p.a_is2 + (int64_t)t * p.lda +
+                                                m0 + lcol);
         const int tb = t * p.stride + shift;
         if (tb >= 0 && tb < p.T_b && n0 + lcol < p.N)
-          vb = *reinterpret_cast<const float4*>(Bm + (int64_t)item * p.b_is + (int64_t)tb * p.ldb + n0 + lcol);
+          vb = *reinterpret_cast<const float4*>(Bm + (int64_t)i1 * p.b_is + (int64_t)i2 * p.b_is2 + (int64_t)tb * p.ldb +
+                                                n0 + lcol);
       }
       ra[i] = va;
       rb[i] = vb;
@@ -193,7 +198,7 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   // sits in those pad columns only reaches output rows >= M, which are not stored
   SRN_CHECK_ARG(p.N % 4 == 0 && p.lda % 4 == 0 && p.lda >= (p.M + 3) / 4 * 4 && p.ldb % 4 == 0 && p.ldc % 4 == 0 &&
                     p.a_bs % 4 == 0 && p.a_hs % 4 == 0 && p.a_is % 4 == 0 && p.b_bs % 4 == 0 && p.b_hs % 4 == 0 &&
-                    p.b_is % 4 == 0 && p.out_bs % 4 == 0 && p.out_hs % 4 == 0 &&
+                    p.b_is % 4 == 0 && p.a_is2 % 4 == 0 && p.b_is2 % 4 == 0 && p.out_bs % 4 == 0 && p.out_hs % 4 == 0 &&
                     ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b) |
                       reinterpret_cast<uintptr_t>(p.out)) & 15) == 0,
                 "tn_gemm: N, leading dimensions and strides must be multiples of 4 floats (lda >= roundup(M, 4)), pointers "

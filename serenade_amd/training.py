@@ -93,7 +93,8 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dgrad: dX[t] = sum_j dY[(t - taps[j]) / stride] W_j over the taps that divide -> a conv of dY with the
             # transposed weights Wd[c][j][n] = W[n][j][c]; with stride 2 one launch per output-row parity
-            wd = w.view(N, nt, C).permute(2, 1, 0).contiguous()  # (C, nt, N)
+            wd = torch.empty(C, nt, N, device=dy.device, dtype=torch.float32)  # LDS tile transposes, one batch per tap
+            _call("srn_transpose_ct", w, wd, nt, N, C, C, nt * C, N, nt * N)
             dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
             if stride == 1:
                 _launch_conv(dy, wd.view(C, nt * N), None, dx, [-o for o in taps], B, T_out, T, N, C)
@@ -167,13 +168,35 @@ class _AddRowBias(torch.autograd.Function):
         return dy, _colsum(dy)
 
 
+class _PackConv(torch.autograd.Function):
+    """(N, C, k) -> (N, k * C_pad): per output channel a (C, k) -> (k, C) LDS tile transpose (srn_transpose_ct), zero pad
+    columns; backward the transpose back.  (torch's strided copy of the same permute ran at < 1 TB/s and there are
+    three of them per weight per step: pack, its gradient, and the dgrad operand.)"""
+
+    @staticmethod
+    def forward(ctx, w, c_pad):
+        n, c, k = w.shape
+        ctx.dims = (n, c, k, c_pad)
+        w = w.contiguous()
+        out = (torch.zeros if c_pad > c else torch.empty)(n, k * c_pad, device=w.device, dtype=torch.float32)
+        _call("srn_transpose_ct", w, out, n, c, k, c * k, k, k * c_pad, c_pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        n, c, k, c_pad = ctx.dims
+        dw = torch.empty(n, c, k, device=dp.device, dtype=torch.float32)
+        _call("srn_transpose_ct", dp.contiguous(), dw, n, k, c, k * c_pad, c_pad, c * k, k)
+        return dw, None
+
+
 def pack_conv(w, c_pad=None):
-    """torch Conv1d weight (N, C, k) -> (N, k * C_pad), differentiable (a permute + pad)."""
+    """torch Conv1d weight (N, C, k) -> (N, k * C_pad), differentiable."""
     n, c, k = w.shape
-    wp = w.permute(0, 2, 1)
-    if c_pad is not None and c_pad > c:
-        wp = F.pad(wp, (0, c_pad - c))
-    return wp.reshape(n, -1)
+    c_pad = c if c_pad is None else max(int(c_pad), c)
+    if k == 1 and c_pad == c:
+        return w.reshape(n, c)  # a view
+    return _PackConv.apply(w, c_pad)
 
 
 # =====================================================================================================================
@@ -323,6 +346,190 @@ class _AttnCore(torch.autograd.Function):
 
 def attention_core(qkv, lens, n_head):
     return _AttnCore.apply(qkv.contiguous(), lens, n_head)
+
+
+# =====================================================================================================================
+#  GST pieces: Conv2d(k3, s2, p1), BatchNorm2d(training) + ReLU, GRU (last state), style-token attention
+# =====================================================================================================================
+class _Conv2dS2(torch.autograd.Function):
+    """y (B, Ho, Wo, Co) = Conv2d(k 3, stride 2, pad 1, no bias) of channels-last x (B, H, W, Cp) with the reference's
+    weight (Co, Ci, 3, 3), Ci <= Cp.  For one kernel row kh the op is a stride-2, three-tap conv along W over input row
+    2 ho + kh - 1, batched over (b, ho): three srn_conv_gemm launches forward (as the inference path, models.py), six
+    for dX (two output-column parities per kernel row, accumulated), three srn_tn_gemm for dW."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _require_cuda(x, "training.conv2d_s2")
+        B, H, W, Cp = x.shape
+        Co, Ci = w.shape[0], w.shape[1]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dev = x.device
+        xp = torch.zeros(B, H + 2, W, Cp, device=dev, dtype=torch.float32)  # one zero row above and below
+        xp[:, 1:H + 1] = x
+        wk = torch.zeros(3, Co, 3, Cp, device=dev, dtype=torch.float32)     # [kh][co][kw][ci]
+        wk[:, :, :, :Ci] = w.permute(2, 0, 3, 1)
+        wk = wk.view(3, Co, 3 * Cp)
+        y = torch.empty(B, Ho, Wo, Co, device=dev, dtype=torch.float32)
+        for j, kh in enumerate((1, 0, 2)):
+            kw = dict(in0=(xp, kh * W * Cp), w=wk[kh], out=y, n_batch=B, n_head=Ho, T_in=W, T_out=Wo, C_in=Cp, N=Co,
+                      in0_bs=(H + 2) * W * Cp, in0_hs=2 * W * Cp, ld_in0=Cp, ldw=3 * Cp, out_bs=Ho * Wo * Co,
+                      out_hs=Wo * Co, ld_out=Co, taps=[-1, 0, 1], in_stride=2, precision=_lib.PREC_FP32)
+            if j:
+                kw.update(res=y, res_mode=ops.RES_ADD, res_bs=Ho * Wo * Co, res_hs=Wo * Co, ld_res=Co)
+            ConvOp(**kw)()
+        ctx.save_for_backward(xp, wk)
+        ctx.dims = (B, H, W, Cp, Co, Ci, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wk = ctx.saved_tensors
+        B, H, W, Cp, Co, Ci, Ho, Wo = ctx.dims
+        dev = dy.device
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.zeros(B, H + 2, W, Cp, device=dev, dtype=torch.float32)
+            wd = torch.empty(3, Cp, 3, Co, device=dev, dtype=torch.float32)  # [kh][ci][kw][co]
+            for kh in range(3):  # per kernel row: batch = kw, (Co, Cp) -> (Cp, Co) tiles
+                _call("srn_transpose_ct", (wk, kh * Co * 3 * Cp), (wd, kh * Cp * 3 * Co), 3, Co, Cp, Cp, 3 * Cp, Co,
+                      3 * Co)
+            for kh in range(3):
+                for ph in range(2):
+                    sel = [j for j, o in enumerate((-1, 0, 1)) if (ph - o) % 2 == 0]
+                    rows = (W - ph + 1) // 2
+                    if rows <= 0:
+                        continue
+                    wsel = torch.stack([wd[kh, :, j, :] for j in sel], dim=1).reshape(Cp, len(sel) * Co)
+                    out = (dxp, kh * W * Cp)
+                    ConvOp(in0=dy, w=wsel, out=out, n_batch=B, n_head=Ho, T_in=Wo, T_out=rows, C_in=Co, N=Cp,
+                           in0_bs=Ho * Wo * Co, in0_hs=Wo * Co, ld_in0=Co, ldw=len(sel) * Co, out_bs=(H + 2) * W * Cp,
+                           out_hs=2 * W * Cp, ld_out=Cp, taps=[(ph - (-1, 0, 1)[j]) // 2 for j in sel], out_t_stride=2,
+                           out_t_off=ph, res=out, res_mode=ops.RES_ADD, res_bs=(H + 2) * W * Cp, res_hs=2 * W * Cp,
+                           ld_res=Cp, precision=_lib.PREC_FP32)()
+            dx = dxp[:, 1:H + 1]
+        if ctx.needs_input_grad[1]:
+            dwk = torch.empty(3, Co, 3 * Cp, device=dev, dtype=torch.float32)
+            for kh in range(3):
+                TnGemmOp(a=dy, b=(xp, kh * W * Cp), out=(dwk, kh * Co * 3 * Cp), n_items=B * Ho, T_a=Wo, T_b=W, M=Co, N=Cp,
+                         lda=Co, ldb=Cp, ldc=3 * Cp, shifts=(-1, 0, 1), stride=2, n_inner=Ho, a_is=Ho * Wo * Co,
+                         a_is2=Wo * Co, b_is=(H + 2) * W * Cp, b_is2=2 * W * Cp)()
+            dw = dwk.view(3, Co, 3, Cp)[:, :, :, :Ci].permute(1, 3, 0, 2)  # -> (Co, Ci, kh, kw)
+        return dx, dw
+
+
+def conv2d_s2(x, w):
+    return _Conv2dS2.apply(x.contiguous(), w)
+
+
+class _BnRelu(torch.autograd.Function):
+    """relu(BatchNorm(x)) over the rows of channels-last x (..., C) with batch statistics; running statistics (when
+    given) move like nn.BatchNorm2d's (momentum 0.1)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum):
+        _require_cuda(x, "training.bn_relu")
+        C = x.shape[-1]
+        rows = x.numel() // C
+        x = x.contiguous()
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        dev = x.device
+        part = torch.empty(_bn_chunks(rows) * 2 * C, device=dev, dtype=torch.float32)
+        stats = torch.empty(2, C, device=dev, dtype=torch.float32)
+        y = torch.empty_like(x)
+        _call("srn_bn_relu_fwd", x, gamma, beta, run_mean, run_var, part, stats, y, rows, C, eps, momentum)
+        ctx.save_for_backward(x, y, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, stats, gamma = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dev = dy.device
+        part = torch.empty(_bn_chunks(rows) * 2 * C, device=dev, dtype=torch.float32)
+        sums = torch.empty(2, C, device=dev, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        _call("srn_bn_relu_bwd", x, y, dy.contiguous(), stats, gamma, part, sums, dx, rows, C)
+        return dx, sums[1], sums[0], None, None, None, None
+
+
+def _bn_chunks(rows):
+    return (rows + 63) // 64  # srn_bn_chunks
+
+
+def bn_relu(x, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):
+    return _BnRelu.apply(x, gamma, beta, run_mean, run_var, eps, momentum)
+
+
+class _GruLast(torch.autograd.Function):
+    """last hidden state of nn.GRU (one layer, zero initial state) given gi = x W_ih^T + b_ih (B, T, 3H)."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh):
+        _require_cuda(gi, "training.gru_last")
+        B, T, G = gi.shape
+        H = G // 3
+        dev = gi.device
+        gi, w_hh = gi.contiguous(), w_hh.contiguous()
+        w_hh_t = torch.empty(H, G, device=dev, dtype=torch.float32)
+        _call("srn_transpose_ct", w_hh, w_hh_t, 1, G, H, 0, H, 0, G)
+        hs = torch.empty(B, T + 1, H, device=dev, dtype=torch.float32)
+        gates = torch.empty(B, T, 4 * H, device=dev, dtype=torch.float32)
+        _call("srn_gru_train_fwd", gi, w_hh_t, b_hh.contiguous(), hs, gates, B, T, H)
+        ctx.save_for_backward(w_hh, hs, gates)
+        return hs[:, T].clone()
+
+    @staticmethod
+    def backward(ctx, dh):
+        w_hh, hs, gates = ctx.saved_tensors
+        B, T1, H = hs.shape
+        T, G = T1 - 1, 3 * H
+        dev = dh.device
+        dgi = torch.empty(B, T, G, device=dev, dtype=torch.float32)
+        dgh = torch.empty(B, T, G, device=dev, dtype=torch.float32)
+        _call("srn_gru_train_bwd", dh.contiguous(), w_hh, hs, gates, dgi, dgh, B, T, H)
+        dw = torch.empty(G, H, device=dev, dtype=torch.float32)
+        TnGemmOp(a=dgh, b=hs, out=dw, n_items=B, T_a=T, T_b=T, M=G, N=H, lda=G, ldb=H, ldc=H, a_is=T * G,
+                 b_is=(T + 1) * H)()
+        return dgi, dw, _colsum(dgh.view(B * T, G))
+
+
+def gru_last(gi, w_hh, b_hh):
+    return _GruLast.apply(gi, w_hh, b_hh)
+
+
+class _TokenAttn(torch.autograd.Function):
+    """gst/attention.py:110-184 for one query per item: q (B, F), k / v (n_tok, F) -> context (B, F)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n_head):
+        _require_cuda(q, "training.token_attention")
+        B, Fd = q.shape
+        n_tok = k.shape[0]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        p = torch.empty(B, n_head, n_tok, device=q.device, dtype=torch.float32)
+        out = torch.empty(B, Fd, device=q.device, dtype=torch.float32)
+        _call("srn_token_attn_fwd", q, k, v, p, out, B, n_tok, Fd, n_head)
+        ctx.save_for_backward(q, k, v, p)
+        ctx.n_head = n_head
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, k, v, p = ctx.saved_tensors
+        B, Fd = q.shape
+        n_tok = k.shape[0]
+        dev = q.device
+        dq = torch.empty(B, Fd, device=dev, dtype=torch.float32)
+        dkp = torch.empty(B, n_tok * Fd, device=dev, dtype=torch.float32)
+        dvp = torch.empty(B, n_tok * Fd, device=dev, dtype=torch.float32)
+        _call("srn_token_attn_bwd", dctx.contiguous(), q, k, v, p, dq, dkp, dvp, B, n_tok, Fd, ctx.n_head)
+        return dq, _colsum(dkp).view(n_tok, Fd), _colsum(dvp).view(n_tok, Fd), None
+
+
+def token_attention(q, k, v, n_head):
+    return _TokenAttn.apply(q, k, v, n_head)
 
 
 # =====================================================================================================================
@@ -670,41 +877,42 @@ class TrainSerenade:
         return conv1d(_reflect_pad_rows(F.leaky_relu(h, 0.2), 3), pack_conv(self._wn(last)), P[last + ".bias"],
                       range(7), T_out=T)
 
-    # ---- GST (library path) ----------------------------------------------------------------------------------------
+    # ---- GST -------------------------------------------------------------------------------------------------------
     def gst(self, speech, n_head=4):
-        """StyleEncoder.forward (style_encoder.py:78-91,171-191,235-252) on torch GPU ops"""
+        """StyleEncoder.forward (style_encoder.py:78-91,171-191,235-252), channels-last, own kernels in both directions:
+        Conv2d(k3, s2, p1) as one stride-2 three-tap contraction along the mel axis per kernel row (srn_conv_gemm forward
+        and dgrad, srn_tn_gemm wgrad), BatchNorm2d(training) + ReLU (srn_bn_relu_*), the GRU's input projection as a
+        linear + srn_gru_train_* for the recurrence / BPTT, the token attention's four linears + srn_token_attn_*."""
         P, Bf = self.params, self.buffers
         r = "gst.ref_enc."
-        h = speech.unsqueeze(1)
+        B, T, F0 = speech.shape
+        h = F.pad(speech.to(torch.float32).unsqueeze(-1), (0, 3))  # (B, H = T, W = 80, C = 1 padded to 4)
         i = 0
         while f"{r}convs.{3 * i}.weight" in P:
             c, b = f"{r}convs.{3 * i}", f"{r}convs.{3 * i + 1}"
-            h = F.conv2d(h, P[c + ".weight"], None, stride=2, padding=1)
-            h = F.batch_norm(h, Bf[b + ".running_mean"], Bf[b + ".running_var"], P[b + ".weight"], P[b + ".bias"],
-                             self.training, 0.1, 1e-5)
-            if self.training and b + ".num_batches_tracked" in Bf:
+            h = conv2d_s2(h, P[c + ".weight"])
+            rm, rv = (Bf[b + ".running_mean"], Bf[b + ".running_var"]) if self.training else (None, None)
+            if not self.training:
+                raise NotImplementedError("TrainSerenade.gst runs BatchNorm on batch statistics (training mode)")
+            h = bn_relu(h, P[b + ".weight"], P[b + ".bias"], rm, rv)
+            if b + ".num_batches_tracked" in Bf:
                 Bf[b + ".num_batches_tracked"] += 1
-            h = F.relu(h)
             i += 1
-        h = h.transpose(1, 2)
-        bsz, tlen = h.shape[0], h.shape[1]
-        xs = h.contiguous().view(bsz, tlen, -1)
+        bsz, tlen, wdim, cdim = h.shape
+        xs = h.reshape(bsz, tlen, wdim * cdim)  # features ordered (w, c); the reference's view orders them (c, w)
         wih, whh = P[r + "gru.weight_ih_l0"], P[r + "gru.weight_hh_l0"]
-        bih, bhh = P[r + "gru.bias_ih_l0"], P[r + "gru.bias_hh_l0"]
-        # torch.nn.GRU's own fused op (MIOpen on the GPU): last hidden state, gate order r, z, n
-        _, hn = torch._VF.gru(xs, xs.new_zeros(1, bsz, whh.shape[1]), [wih, whh, bih, bhh], True, 1, 0.0, self.training,
-                              False, True)
-        hh = hn[0]
+        wih = wih.view(-1, cdim, wdim).permute(0, 2, 1).reshape(wih.shape[0], -1)
+        gi = conv1d(xs, wih, P[r + "gru.bias_ih_l0"])
+        hh = gru_last(gi, whh, P[r + "gru.bias_hh_l0"])
         m = "gst.stl.mha."
         toks = torch.tanh(P["gst.stl.gst_embs"])
-        q = hh @ P[m + "linear_q.weight"].t() + P[m + "linear_q.bias"]
-        k = toks @ P[m + "linear_k.weight"].t() + P[m + "linear_k.bias"]
-        v = toks @ P[m + "linear_v.weight"].t() + P[m + "linear_v.bias"]
-        nf = q.shape[-1]
-        dk = nf // n_head
-        scores = torch.einsum("bhd,thd->bht", q.view(bsz, n_head, dk), k.view(-1, n_head, dk)) / math.sqrt(dk)
-        ctx = torch.einsum("bht,thd->bhd", torch.softmax(scores, dim=-1), v.view(-1, n_head, dk)).reshape(bsz, nf)
-        return ctx @ P[m + "linear_out.weight"].t() + P[m + "linear_out.bias"]
+        q = conv1d(hh, P[m + "linear_q.weight"], P[m + "linear_q.bias"])
+        k = conv1d(F.pad(toks, (0, (-toks.shape[1]) % 4)), F.pad(P[m + "linear_k.weight"], (0, (-toks.shape[1]) % 4)),
+                   P[m + "linear_k.bias"])
+        v = conv1d(F.pad(toks, (0, (-toks.shape[1]) % 4)), F.pad(P[m + "linear_v.weight"], (0, (-toks.shape[1]) % 4)),
+                   P[m + "linear_v.bias"])
+        ctx = token_attention(q, k, v, n_head)
+        return conv1d(ctx, P[m + "linear_out.weight"], P[m + "linear_out.bias"])
 
     def draw_segment(self, T):
         """(seg_start, seg_len) of the infill segment, drawn like serenade.py:117-119 (python `random`)"""

@@ -363,6 +363,74 @@ def emul_call(name, a):
         mv, rv = _v(mean, B * G).reshape(B, G), _v(rstd, B * G).reshape(B, G)
         for b in range(B):
             mv[b], rv[b] = _group_stats(part, b, T, C, G, eps)
+    elif name == "srn_bn_relu_fwd":
+        x, gamma, beta, rm, rv, part, stats, y, rows, C, eps, mom = a
+        xv = _v(x, rows * C).reshape(rows, C).double()
+        mean, var = xv.mean(0), xv.var(0, unbiased=False)
+        sv = _v(stats, 2 * C).reshape(2, C)
+        sv[0], sv[1] = mean.float(), (1.0 / torch.sqrt(var + eps)).float()
+        _v(y, rows * C).reshape(rows, C)[:] = torch.relu((xv - mean) / torch.sqrt(var + eps) * _v(gamma, C).double()
+                                                         + _v(beta, C).double()).float()
+        if rm is not None:
+            unb = var * (rows / (rows - 1)) if rows > 1 else var
+            _v(rm, C)[:] = ((1 - mom) * _v(rm, C).double() + mom * mean).float()
+            _v(rv, C)[:] = ((1 - mom) * _v(rv, C).double() + mom * unb).float()
+    elif name == "srn_bn_relu_bwd":
+        x, y, dy, stats, gamma, part, sums, dx, rows, C = a
+        xv, yv, gv = (_v(t, rows * C).reshape(rows, C).double() for t in (x, y, dy))
+        sv = _v(stats, 2 * C).reshape(2, C).double()
+        g = gv * (yv > 0)
+        xhat = (xv - sv[0]) * sv[1]
+        s0, s1 = g.sum(0), (g * xhat).sum(0)
+        ov = _v(sums, 2 * C).reshape(2, C)
+        ov[0], ov[1] = s0.float(), s1.float()
+        _v(dx, rows * C).reshape(rows, C)[:] = (_v(gamma, C).double() * sv[1] * (g - (s0 + xhat * s1) / rows)).float()
+    elif name == "srn_gru_train_fwd":
+        gi, w_hh_t, b_hh, hs, gates, B, T, H = a
+        giv = _v(gi, B * T * 3 * H).reshape(B, T, 3 * H)
+        wt, bh = _v(w_hh_t, H * 3 * H).reshape(H, 3 * H), _v(b_hh, 3 * H)
+        hv, gv = _v(hs, B * (T + 1) * H).reshape(B, T + 1, H), _v(gates, B * T * 4 * H).reshape(B, T, 4 * H)
+        hv[:, 0] = 0
+        for t in range(T):
+            gh = hv[:, t] @ wt + bh
+            r = torch.sigmoid(giv[:, t, :H] + gh[:, :H])
+            z = torch.sigmoid(giv[:, t, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(giv[:, t, 2 * H:] + r * gh[:, 2 * H:])
+            hv[:, t + 1] = (1 - z) * n + z * hv[:, t]
+            gv[:, t] = torch.cat([r, z, n, gh[:, 2 * H:]], dim=1)
+    elif name == "srn_gru_train_bwd":
+        dh_last, w_hh, hs, gates, dgi, dgh, B, T, H = a
+        w = _v(w_hh, 3 * H * H).reshape(3 * H, H)
+        hv, gv = _v(hs, B * (T + 1) * H).reshape(B, T + 1, H), _v(gates, B * T * 4 * H).reshape(B, T, 4 * H)
+        di, dg = _v(dgi, B * T * 3 * H).reshape(B, T, 3 * H), _v(dgh, B * T * 3 * H).reshape(B, T, 3 * H)
+        d = _v(dh_last, B * H).reshape(B, H).clone()
+        for t in range(T - 1, -1, -1):
+            r, z, n, ghn = gv[:, t, :H], gv[:, t, H:2 * H], gv[:, t, 2 * H:3 * H], gv[:, t, 3 * H:]
+            dn = d * (1 - z) * (1 - n * n)
+            dz = d * (hv[:, t] - n) * z * (1 - z)
+            dr = dn * ghn * r * (1 - r)
+            di[:, t] = torch.cat([dr, dz, dn], dim=1)
+            dg[:, t] = torch.cat([dr, dz, dn * r], dim=1)
+            d = d * z + dg[:, t] @ w
+    elif name == "srn_token_attn_fwd":
+        q, k, v, p, ctx, B, n_tok, F_, nh = a
+        dk = F_ // nh
+        qv = _v(q, B * F_).reshape(B, nh, dk)
+        kv, vv = _v(k, n_tok * F_).reshape(n_tok, nh, dk), _v(v, n_tok * F_).reshape(n_tok, nh, dk)
+        pr = torch.softmax(torch.einsum("bhd,thd->bht", qv, kv) / math.sqrt(dk), dim=-1)
+        _v(p, B * nh * n_tok).reshape(B, nh, n_tok)[:] = pr
+        _v(ctx, B * F_).reshape(B, nh, dk)[:] = torch.einsum("bht,thd->bhd", pr, vv)
+    elif name == "srn_token_attn_bwd":
+        dctx, q, k, v, p, dq, dkp, dvp, B, n_tok, F_, nh = a
+        dk = F_ // nh
+        dc, qv = _v(dctx, B * F_).reshape(B, nh, dk), _v(q, B * F_).reshape(B, nh, dk)
+        kv, vv = _v(k, n_tok * F_).reshape(n_tok, nh, dk), _v(v, n_tok * F_).reshape(n_tok, nh, dk)
+        pr = _v(p, B * nh * n_tok).reshape(B, nh, n_tok)
+        dp = torch.einsum("bhd,thd->bht", dc, vv)
+        ds = pr * (dp - (pr * dp).sum(-1, keepdim=True)) / math.sqrt(dk)
+        _v(dq, B * F_).reshape(B, nh, dk)[:] = torch.einsum("bht,thd->bhd", ds, kv)
+        _v(dkp, B * n_tok * F_).reshape(B, n_tok, nh, dk)[:] = torch.einsum("bht,bhd->bthd", ds, qv)
+        _v(dvp, B * n_tok * F_).reshape(B, n_tok, nh, dk)[:] = torch.einsum("bht,bhd->bthd", pr, dc)
     elif name == "srn_colsum":
         x, part, out, B, R, N, ld = a
         _v(out, B * N).reshape(B, N)[:] = _v(x, B * R * ld).reshape(B, R, ld)[:, :, :N].sum(1)
@@ -443,9 +511,11 @@ def emul_tn_gemm(kw):
         for zh in range(g("n_head")):
             for j, sh in enumerate(g("shifts")):
                 acc = torch.zeros(M, N, dtype=torch.float64)
+                ninner = max(1, g("n_inner", 1))
                 for it in range(g("n_items")):
-                    a0 = oa + zb * g("a_bs") + zh * g("a_hs") + it * g("a_is")
-                    b0 = ob + zb * g("b_bs") + zh * g("b_hs") + it * g("b_is")
+                    i1, i2 = divmod(it, ninner)
+                    a0 = oa + zb * g("a_bs") + zh * g("a_hs") + i1 * g("a_is") + i2 * g("a_is2", 0)
+                    b0 = ob + zb * g("b_bs") + zh * g("b_hs") + i1 * g("b_is") + i2 * g("b_is2", 0)
                     am = torch.as_strided(a, (T_a, M), (g("lda"), 1), a0).double()
                     tb = torch.arange(T_a) * stride + sh
                     ok = (tb >= 0) & (tb < T_b)
@@ -477,7 +547,7 @@ class installed:
         def tn_init(self_, **kw):  # no library call (workspace query) on the CPU
             kw.setdefault("shifts", (0,))
             for k, v in dict(stride=1, n_batch=1, n_head=1, a_bs=0, a_hs=0, a_is=0, b_bs=0, b_hs=0, b_is=0, out_bs=0,
-                             out_hs=0, alpha=1.0).items():
+                             out_hs=0, alpha=1.0, n_inner=1, a_is2=0, b_is2=0).items():
                 kw.setdefault(k, v)
             self_.kw = kw
         ops.TnGemmOp.__init__ = tn_init

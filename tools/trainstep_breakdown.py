@@ -12,8 +12,10 @@ import sys
 def cat(n):
     if "conv_fast" in n or "conv_gemm_kernel" in n or "splitk" in n or "conv_halo" in n:
         return "own contraction kernels (srn_conv_gemm)"
+    if "tn_gemm" in n or "tn_reduce" in n:
+        return "own time-contraction kernels (srn_tn_gemm: wgrad / dK / dV)"
     if n.startswith("Cijk") or "rocblas" in n:
-        return "rocBLAS (wgrad, dK, dV)"
+        return "rocBLAS"
     if "anonymous namespace" in n and "at::native" not in n:
         return "own other kernels (train.hip, norm_act.hip)"
     low = n.lower()
@@ -49,7 +51,7 @@ def main():
         for n, v in c.most_common():
             lines.append(f"{n},{k[n]},{v / 1e6:.3f},{100 * v / tot:.1f}")
         print(lines[-len(c) - 1])
-        for n, v in ck.most_common(14):
+        for n, v in ck.most_common(40):
             print(f"   {v / 1e3:8.1f} us {kk[n]:4d}  {n}")
     print("\n".join(lines))
     if len(sys.argv) > 2:
