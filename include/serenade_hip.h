@@ -445,6 +445,12 @@ int srn_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float
 /* dx, and sums (2, C) = (dbeta, dgamma). */
 int srn_bn_relu_bwd(const float* x, const float* y, const float* dy, const float* stats, const float* gamma,
                     float* partial, float* sums, float* dx, int64_t rows, int C, void* stream);
+/* Conv2d(k 3, stride 2, pad 1) on channels-last (B, H, W, C) as a plain GEMM: col[(b, ho, wo), (kh, kw, c)] =
+ * x[b, 2 ho + kh - 1, 2 wo + kw - 1, c] (zero outside), row stride ld >= 9 C (pad columns are not written).  The
+ * per-(b, ho) form of the inference path leaves 64-row tiles mostly empty once Wo <= 20; flattened, every layer is
+ * one well-shaped contraction per direction.  srn_col2im_s2 is the transpose of the gather (the dX side). */
+int srn_im2col_s2(const float* x, float* col, int B, int H, int W, int C, int ld, void* stream);
+int srn_col2im_s2(const float* col, float* dx, int B, int H, int W, int C, int ld, void* stream);
 /* nn.GRU recurrence (gate order r, z, n) on gi = x W_ih^T + b_ih (B, T, 3H), zero initial state: hs (B, T+1, H) all
  * hidden states, gates (B, T, 4H) = [r | z | n | W_hn h + b_hn].  w_hh_t = W_hh transposed (H, 3H). */
 int srn_gru_train_fwd(const float* gi, const float* w_hh_t, const float* b_hh, float* hs, float* gates, int B, int T,

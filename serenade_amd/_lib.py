@@ -137,6 +137,8 @@ _SIGS = {
     "srn_bn_chunks": (c_int, [c_int64]),
     "srn_bn_relu_fwd": (c_int, [_P] * 8 + [c_int64, c_int, c_float, c_float, _P]),
     "srn_bn_relu_bwd": (c_int, [_P] * 8 + [c_int64, c_int, _P]),
+    "srn_im2col_s2": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
+    "srn_col2im_s2": (c_int, [_P, _P] + [c_int] * 5 + [_P]),
     "srn_gru_train_fwd": (c_int, [_P] * 5 + [c_int] * 3 + [_P]),
     "srn_gru_train_bwd": (c_int, [_P] * 6 + [c_int] * 3 + [_P]),
     "srn_token_attn_fwd": (c_int, [_P] * 5 + [c_int] * 4 + [_P]),

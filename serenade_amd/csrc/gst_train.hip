@@ -17,7 +17,8 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
-constexpr int BN_ROWS = 64;  // rows per partial-sum chunk
+// rows per partial-sum chunk: at most ~256 chunks, so the finishing kernel's ordered sum stays short
+__host__ __device__ inline int64_t bn_rows_per_chunk(int64_t R) { return R <= 256 * 16 ? 16 : (R + 255) / 256; }
 
 // mode 0: partial[chunk][0][c] = sum x, [1][c] = sum x^2
 // mode 1: g = dy * (y > 0): [0][c] = sum g, [1][c] = sum g * xhat,  xhat = (x - mean) * rstd
@@ -26,7 +27,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          float* __restrict__ partial, int64_t R, int C, int mode) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS, r1 = min(R, r0 + BN_ROWS);
+  const int64_t per = bn_rows_per_chunk(R);
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(R, r0 + per);
   float s0 = 0.f, s1 = 0.f;
   if (mode == 0) {
     for (int64_t r = r0; r < r1; ++r) {
@@ -106,6 +108,53 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       }
     }
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col (k3 s2 p1)
+__global__ __launch_bounds__(256) void im2col_s2_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H,
+                                                        int W, int C, int ld) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, c4 = C / 4;
+  const int64_t total = (int64_t)B * Ho * Wo * 9 * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c4);
+    int64_t r = i / c4;
+    const int k = (int)(r % 9);
+    r /= 9;
+    const int wo = (int)(r % Wo);
+    const int64_t bh = r / Wo;
+    const int ho = (int)(bh % Ho), b = (int)(bh / Ho);
+    const int h = 2 * ho + k / 3 - 1, w = 2 * wo + k % 3 - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h >= 0 && h < H && w >= 0 && w < W)
+      v = *reinterpret_cast<const float4*>(x + (((int64_t)b * H + h) * W + w) * C + c * 4);
+    *reinterpret_cast<float4*>(col + r * ld + k * C + c * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ col, float* __restrict__ dx, int B,
+                                                        int H, int W, int C, int ld) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, c4 = C / 4;
+  const int64_t total = (int64_t)B * H * W * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % c4);
+    int64_t r = i / c4;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H), b = (int)(r / H);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + 1 - kh;
+      if (hh < 0 || (hh & 1) || hh / 2 >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + 1 - kw;
+        if (ww < 0 || (ww & 1) || ww / 2 >= Wo) continue;
+        const float4 v = *reinterpret_cast<const float4*>(
+            col + (((int64_t)b * Ho + hh / 2) * Wo + ww / 2) * ld + (kh * 3 + kw) * C + c * 4);
+        a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(dx + i * 4) = a;
   }
 }
 
@@ -275,7 +324,11 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int srn_bn_chunks(int64_t rows) { return (int)((rows + BN_ROWS - 1) / BN_ROWS); }
+extern "C" int srn_bn_chunks(int64_t rows) {
+  const int64_t per = bn_rows_per_chunk(rows);
+  return (int)((rows + per - 1) / per);
+}
+
 
 extern "C" int srn_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
                                float* partial, float* stats, float* y, int64_t rows, int C, float eps, float momentum,
@@ -313,6 +366,24 @@ extern "C" int srn_bn_relu_bwd(const float* x, const float* y, const float* dy, 
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, stats, (const float*)sums, gamma,
                      (const float*)nullptr, dx, rows, C, 1);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_im2col_s2(const float* x, float* col, int B, int H, int W, int C, int ld, void* stream) {
+  SRN_CHECK_ARG(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ld >= 9 * C && ld % 4 == 0, "im2col_s2: bad args");
+  const int64_t total = (int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 9 * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(im2col_s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, col, B, H, W, C, ld);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_col2im_s2(const float* col, float* dx, int B, int H, int W, int C, int ld, void* stream) {
+  SRN_CHECK_ARG(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ld >= 9 * C && ld % 4 == 0, "col2im_s2: bad args");
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(col2im_s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, col, dx, B, H, W, C, ld);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -301,7 +301,7 @@ class _AttnCore(torch.autograd.Function):
                out_hs=L * Lp, ld_out=Lp, alpha=alpha, precision=_lib.PREC_FP32)()
         _call("srn_softmax_rows", P, lens, B * H, H, L, Lp)
         vt = alloc(B, inner, Lp, device=dev, dtype=torch.float32)  # V^T per head: (hd, Lp) k-major
-        vt[:, :, :L] = qkv[:, :, 2 * inner:].transpose(1, 2)
+        _call("srn_transpose_ct", (qkv, 2 * inner), vt, B, L, inner, L * three, three, inner * Lp, Lp)
         o = torch.empty(B, L, inner, device=dev, dtype=torch.float32)
         ConvOp(in0=P, w=vt, out=o, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
                in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * inner, out_hs=hd,
@@ -330,7 +330,7 @@ class _AttnCore(torch.autograd.Function):
         _call("srn_softmax_bwd", P, dS, B * H * L, L, Lp, 1.0 / math.sqrt(hd))
         # dQ = dS K: contraction over keys, K^T per head as the k-major operand
         kt = alloc(B, inner, Lp, device=dev, dtype=torch.float32)
-        kt[:, :, :L] = qkv[:, :, inner:2 * inner].transpose(1, 2)
+        _call("srn_transpose_ct", (qkv, inner), kt, B, L, inner, L * three, three, inner * Lp, Lp)
         ConvOp(in0=dS, w=kt, out=dqkv, n_batch=B, n_head=H, T_in=L, T_out=L, C_in=Lp, N=hd, in0_bs=H * L * Lp,
                in0_hs=L * Lp, ld_in0=Lp, w_bs=inner * Lp, w_hs=hd * Lp, ldw=Lp, out_bs=L * three, out_hs=hd,
                ld_out=three, precision=_lib.PREC_FP32)()
@@ -353,9 +353,9 @@ def attention_core(qkv, lens, n_head):
 # =====================================================================================================================
 class _Conv2dS2(torch.autograd.Function):
     """y (B, Ho, Wo, Co) = Conv2d(k 3, stride 2, pad 1, no bias) of channels-last x (B, H, W, Cp) with the reference's
-    weight (Co, Ci, 3, 3), Ci <= Cp.  For one kernel row kh the op is a stride-2, three-tap conv along W over input row
-    2 ho + kh - 1, batched over (b, ho): three srn_conv_gemm launches forward (as the inference path, models.py), six
-    for dX (two output-column parities per kernel row, accumulated), three srn_tn_gemm for dW."""
+    weight (Co, Ci, 3, 3), Ci <= Cp.  srn_im2col_s2 gathers the receptive fields once ((B Ho Wo) x 9 Cp rows, padded to
+    a multiple of 32 columns), then forward, dX (+ srn_col2im_s2) and dW (srn_tn_gemm) are ONE contraction each over
+    all output positions -- the per-(b, ho) form of the inference path wastes its 64-row tiles once Wo <= 20."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -364,57 +364,36 @@ class _Conv2dS2(torch.autograd.Function):
         Co, Ci = w.shape[0], w.shape[1]
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dev = x.device
-        xp = torch.zeros(B, H + 2, W, Cp, device=dev, dtype=torch.float32)  # one zero row above and below
-        xp[:, 1:H + 1] = x
-        wk = torch.zeros(3, Co, 3, Cp, device=dev, dtype=torch.float32)     # [kh][co][kw][ci]
-        wk[:, :, :, :Ci] = w.permute(2, 0, 3, 1)
-        wk = wk.view(3, Co, 3 * Cp)
+        K = _rup(9 * Cp, 32)
+        rows = B * Ho * Wo
+        col = (torch.zeros if K > 9 * Cp else torch.empty)(rows, K, device=dev, dtype=torch.float32)
+        _call("srn_im2col_s2", x, col, B, H, W, Cp, K)
+        wk = torch.zeros(Co, K, device=dev, dtype=torch.float32)  # [co][(kh, kw, ci)]
+        wk[:, :9 * Cp].view(Co, 3, 3, Cp)[..., :Ci] = w.permute(0, 2, 3, 1)
         y = torch.empty(B, Ho, Wo, Co, device=dev, dtype=torch.float32)
-        for j, kh in enumerate((1, 0, 2)):
-            kw = dict(in0=(xp, kh * W * Cp), w=wk[kh], out=y, n_batch=B, n_head=Ho, T_in=W, T_out=Wo, C_in=Cp, N=Co,
-                      in0_bs=(H + 2) * W * Cp, in0_hs=2 * W * Cp, ld_in0=Cp, ldw=3 * Cp, out_bs=Ho * Wo * Co,
-                      out_hs=Wo * Co, ld_out=Co, taps=[-1, 0, 1], in_stride=2, precision=_lib.PREC_FP32)
-            if j:
-                kw.update(res=y, res_mode=ops.RES_ADD, res_bs=Ho * Wo * Co, res_hs=Wo * Co, ld_res=Co)
-            ConvOp(**kw)()
-        ctx.save_for_backward(xp, wk)
-        ctx.dims = (B, H, W, Cp, Co, Ci, Ho, Wo)
+        _launch_conv(col, wk, None, y, [0], 1, rows, rows, K, Co)
+        ctx.save_for_backward(col, wk)
+        ctx.dims = (B, H, W, Cp, Co, Ci, Ho, Wo, K, rows)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xp, wk = ctx.saved_tensors
-        B, H, W, Cp, Co, Ci, Ho, Wo = ctx.dims
+        col, wk = ctx.saved_tensors
+        B, H, W, Cp, Co, Ci, Ho, Wo, K, rows = ctx.dims
         dev = dy.device
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dxp = torch.zeros(B, H + 2, W, Cp, device=dev, dtype=torch.float32)
-            wd = torch.empty(3, Cp, 3, Co, device=dev, dtype=torch.float32)  # [kh][ci][kw][co]
-            for kh in range(3):  # per kernel row: batch = kw, (Co, Cp) -> (Cp, Co) tiles
-                _call("srn_transpose_ct", (wk, kh * Co * 3 * Cp), (wd, kh * Cp * 3 * Co), 3, Co, Cp, Cp, 3 * Cp, Co,
-                      3 * Co)
-            for kh in range(3):
-                for ph in range(2):
-                    sel = [j for j, o in enumerate((-1, 0, 1)) if (ph - o) % 2 == 0]
-                    rows = (W - ph + 1) // 2
-                    if rows <= 0:
-                        continue
-                    wsel = torch.stack([wd[kh, :, j, :] for j in sel], dim=1).reshape(Cp, len(sel) * Co)
-                    out = (dxp, kh * W * Cp)
-                    ConvOp(in0=dy, w=wsel, out=out, n_batch=B, n_head=Ho, T_in=Wo, T_out=rows, C_in=Co, N=Cp,
-                           in0_bs=Ho * Wo * Co, in0_hs=Wo * Co, ld_in0=Co, ldw=len(sel) * Co, out_bs=(H + 2) * W * Cp,
-                           out_hs=2 * W * Cp, ld_out=Cp, taps=[(ph - (-1, 0, 1)[j]) // 2 for j in sel], out_t_stride=2,
-                           out_t_off=ph, res=out, res_mode=ops.RES_ADD, res_bs=(H + 2) * W * Cp, res_hs=2 * W * Cp,
-                           ld_res=Cp, precision=_lib.PREC_FP32)()
-            dx = dxp[:, 1:H + 1]
+            wd = torch.empty(K, Co, device=dev, dtype=torch.float32)
+            _call("srn_transpose_ct", wk, wd, 1, Co, K, 0, K, 0, Co)
+            dcol = torch.empty(rows, K, device=dev, dtype=torch.float32)
+            _launch_conv(dy, wd, None, dcol, [0], 1, rows, rows, Co, K)
+            dx = torch.empty(B, H, W, Cp, device=dev, dtype=torch.float32)
+            _call("srn_col2im_s2", dcol, dx, B, H, W, Cp, K)
         if ctx.needs_input_grad[1]:
-            dwk = torch.empty(3, Co, 3 * Cp, device=dev, dtype=torch.float32)
-            for kh in range(3):
-                TnGemmOp(a=dy, b=(xp, kh * W * Cp), out=(dwk, kh * Co * 3 * Cp), n_items=B * Ho, T_a=Wo, T_b=W, M=Co, N=Cp,
-                         lda=Co, ldb=Cp, ldc=3 * Cp, shifts=(-1, 0, 1), stride=2, n_inner=Ho, a_is=Ho * Wo * Co,
-                         a_is2=Wo * Co, b_is=(H + 2) * W * Cp, b_is2=2 * W * Cp)()
-            dw = dwk.view(3, Co, 3, Cp)[:, :, :, :Ci].permute(1, 3, 0, 2)  # -> (Co, Ci, kh, kw)
+            dwk = torch.empty(Co, K, device=dev, dtype=torch.float32)
+            TnGemmOp(a=dy, b=col, out=dwk, n_items=1, T_a=rows, T_b=rows, M=Co, N=K, lda=Co, ldb=K, ldc=K)()
+            dw = dwk[:, :9 * Cp].view(Co, 3, 3, Cp)[..., :Ci].permute(0, 3, 1, 2)  # -> (Co, Ci, kh, kw)
         return dx, dw
 
 
@@ -455,7 +434,8 @@ class _BnRelu(torch.autograd.Function):
 
 
 def _bn_chunks(rows):
-    return (rows + 63) // 64  # srn_bn_chunks
+    per = 16 if rows <= 256 * 16 else (rows + 255) // 256  # srn_bn_chunks
+    return (rows + per - 1) // per
 
 
 def bn_relu(x, gamma, beta, run_mean=None, run_var=None, eps=1e-5, momentum=0.1):

@@ -385,6 +385,24 @@ def emul_call(name, a):
         ov = _v(sums, 2 * C).reshape(2, C)
         ov[0], ov[1] = s0.float(), s1.float()
         _v(dx, rows * C).reshape(rows, C)[:] = (_v(gamma, C).double() * sv[1] * (g - (s0 + xhat * s1) / rows)).float()
+    elif name in ("srn_im2col_s2", "srn_col2im_s2"):
+        src, dst, B, H, W, C, ld = a
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if name == "srn_im2col_s2":
+            xv = F.pad(_v(src, B * H * W * C).reshape(B, H, W, C), (0, 0, 1, 1, 1, 1))
+            cv = _v(dst, B * Ho * Wo * ld).reshape(B, Ho, Wo, ld)
+            for kh in range(3):
+                for kw in range(3):
+                    k = kh * 3 + kw
+                    cv[..., k * C:(k + 1) * C] = xv[:, kh:kh + 2 * Ho:2, kw:kw + 2 * Wo:2][:, :Ho, :Wo]
+        else:
+            cv = _v(src, B * Ho * Wo * ld).reshape(B, Ho, Wo, ld)
+            acc = torch.zeros(B, H + 2, W + 2, C)
+            for kh in range(3):
+                for kw in range(3):
+                    k = kh * 3 + kw
+                    acc[:, kh:kh + 2 * Ho:2, kw:kw + 2 * Wo:2][:, :Ho, :Wo] += cv[..., k * C:(k + 1) * C]
+            _v(dst, B * H * W * C).reshape(B, H, W, C)[:] = acc[:, 1:H + 1, 1:W + 1]
     elif name == "srn_gru_train_fwd":
         gi, w_hh_t, b_hh, hs, gates, B, T, H = a
         giv = _v(gi, B * T * 3 * H).reshape(B, T, 3 * H)
