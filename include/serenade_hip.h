@@ -324,6 +324,9 @@ int srn_adamw_dyn(float* p, const float* g, float* m, float* v, int64_t n, float
 /* clip_grad_norm_'s total norm: partial[i], i < srn_sumsq_blocks(n) (<= 1024), = fp64 sums of squares of slices of g;
  * the host adds them and takes the root. */
 int srn_sumsq(const float* g, int64_t n, double* partial, void* stream);
+/* the same with a second operand: partial sums of a . b (b == NULL: of a) -- the loss sums of the training step (a torch
+ * reduction of this size zeroes its semaphores with hipMemsetAsync, which a captured hipGraph replays wrongly). */
+int srn_dot(const float* a, const float* b, int64_t n, double* partial, void* stream);
 /* Many small device-to-device copies in one launch (gradients of 262 parameter tensors into the flat gradient buffer):
  * entry e copies len[e] floats from src[e] to dst + off[e].  The table is passed by value in the kernel arguments. */
 #define SRN_COPY_LIST_MAX 160

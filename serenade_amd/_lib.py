@@ -132,6 +132,7 @@ _SIGS = {
     "srn_adamw": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
     "srn_adamw_dyn": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
     "srn_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "srn_dot": (c_int, [_P, _P, c_int64, _P, _P]),
     "srn_multi_copy": (c_int, [POINTER(SrnCopyList), _P, _P]),
     "srn_sumsq_blocks": (c_int, [c_int64]),
     "srn_bn_chunks": (c_int, [c_int64]),

@@ -455,16 +455,19 @@ __global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, c
 }
 
 // sum of squares in fp64: partial[block] for <= 1024 blocks (the host adds them): clip_grad_norm_'s total norm
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+// (h == g: sum of squares; h == nullptr: plain sum; else the dot product -- the loss sums of the training step)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const float* __restrict__ h, int64_t n,
+                                                    double* __restrict__ partial) {
   __shared__ double red[4];
   double acc = 0.0;
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const float4 v = *reinterpret_cast<const float4*>(g + i * 4);
-    acc += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    const float4 w = h ? *reinterpret_cast<const float4*>(h + i * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    acc += ((double)v.x * w.x + (double)v.y * w.y) + ((double)v.z * w.z + (double)v.w * w.w);
   }
   if (blockIdx.x == 0)
-    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)g[i] * g[i];
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)g[i] * (h ? h[i] : 1.f);
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -589,7 +592,15 @@ extern "C" int srn_sumsq_blocks(int64_t n) { return (int)grid_for((n + 7) / 8, 1
 
 extern "C" int srn_sumsq(const float* g, int64_t n, double* partial, void* stream) {
   SRN_CHECK_ARG(g && partial && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "sumsq: bad args");
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)srn_sumsq_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)srn_sumsq_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, g, n, partial);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_dot(const float* a, const float* b, int64_t n, double* partial, void* stream) {
+  SRN_CHECK_ARG(a && partial && n > 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(b) & 15) == 0, "dot: bad args");
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)srn_sumsq_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, partial);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -749,11 +749,35 @@ def _convtranspose_phases(w, stride, padding):
     return out
 
 
+class _Dot(torch.autograd.Function):
+    """sum(a * b) (b None: sum(a)) through srn_dot's fp64 partial sums.  Not a torch reduction: one of this size zeroes
+    its semaphore buffer with hipMemsetAsync, and a captured memset node replays with a corrupted value on this stack
+    (count_memset_nodes); the <= 1024 partials are added by a single-block torch sum, which has no such node."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = a.contiguous().view(-1)
+        b = None if b is None else b.contiguous().view(-1)
+        part = torch.zeros(1024, device=a.device, dtype=torch.float64)
+        _call("srn_dot", a, b, a.numel(), part)
+        ctx.save_for_backward(a, b)
+        return part.sum().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        if b is None:
+            return g.expand_as(a), None
+        return g * b, g * a
+
+
+def _dot(a, b=None):
+    return _Dot.apply(a.reshape(-1), None if b is None else b.reshape(-1))
+
+
 def _total(x):
-    """sum of all elements as a dot product (rocBLAS), not a torch reduction kernel: those return stale / zero results
-    when a captured hipGraph replays them on this stack (see AdamW._grad_norm); same value, same gradient"""
-    f = x.reshape(-1)
-    return torch.dot(f, torch.ones_like(f))
+    """sum of all elements"""
+    return _dot(x)
 
 
 def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1e-4):
@@ -772,7 +796,7 @@ def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1
         den = den * mask_l
         u = u * mask_l
     d = (den - u).reshape(-1)
-    loss = torch.dot(d, d)  # F.mse_loss(den, u, reduction="sum")
+    loss = _dot(d, d)  # F.mse_loss(den, u, reduction="sum")
     denom = _total(mask_l if mask_l is not None else mask.to(d.dtype))
     return loss / (denom * u.shape[1]), y
 
@@ -925,7 +949,7 @@ class TrainSerenade:
         # sum(0.5 * ((logmel - enc)^2 + log 2 pi) * mask) over (B, out, T), written with dot products (see _total)
         diff = (logmel - enc).reshape(-1)
         n_valid = _total(mask)
-        prior = 0.5 * torch.dot(diff * mask.permute(0, 2, 1).expand(B, T, self.output_dim).reshape(-1), diff) \
+        prior = 0.5 * _dot(diff * mask.permute(0, 2, 1).expand(B, T, self.output_dim).reshape(-1), diff) \
             + 0.5 * math.log(2 * math.pi) * self.output_dim * n_valid
         ret["prior_loss"] = prior / (n_valid * self.output_dim)
         targets = logmel * mask_l.permute(0, 2, 1)

@@ -475,6 +475,11 @@ def emul_call(name, a):
         with torch.enable_grad():
             (hv[:, :inner] * F.gelu(hv[:, inner:])).backward(_v(da, rows * inner).reshape(rows, inner))
         _v(dhg, rows * 2 * inner).reshape(rows, 2 * inner)[:] = hv.grad
+    elif name == "srn_dot":
+        x, y, n, part = a
+        pv = _v(part)
+        pv.zero_()
+        pv[0] = (_v(x, n).double() * (1.0 if y is None else _v(y, n).double())).sum()
     elif name == "srn_sumsq":
         g, n, part = a
         pv = _v(part)
