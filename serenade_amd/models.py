@@ -218,7 +218,8 @@ class Decoder(_Packed):
         return P
 
     def plan(self, B, L, n_steps, euler, per_sample_t=False, exact_ragged=False):
-        key = (B, L, n_steps, bool(euler), bool(per_sample_t), bool(exact_ragged), ops.DEFAULT_PRECISION)
+        key = (B, L, n_steps, bool(euler), bool(per_sample_t), bool(exact_ragged), ops.DEFAULT_PRECISION,
+               ops.attention_precision())
         return _lru_get(self._plans, key, 8,
                         lambda: DecoderPlan(self, B, L, n_steps, euler, per_sample_t, exact_ragged))
 
@@ -385,12 +386,12 @@ class DecoderPlan:
                 ol.append(ConvOp(in0=(qkv, q_off), w=(qkv, q_off + inner), out=S, n_batch=nb, n_head=nh, T_in=T,
                                  T_out=T, C_in=hd, N=T, in0_bs=T * 3 * inner, in0_hs=hd, ld_in0=3 * inner,
                                  w_bs=T * 3 * inner, w_hs=hd, ldw=3 * inner, out_bs=nh * T * Tp, out_hs=T * Tp,
-                                 ld_out=Tp, alpha=1.0 / math.sqrt(hd)))
+                                 ld_out=Tp, alpha=1.0 / math.sqrt(hd), precision=ops.attention_precision()))
                 ol.append(ops.softmax_rows_op(S, (ln, b0), nb * nh, nh, T, Tp))
                 ol.append(ConvOp(in0=S, w=(Vt[T], b0 * inner * Tp + h0 * hd * Tp), out=(bufO, b0 * T * inner + h0 * hd),
                                  n_batch=nb, n_head=nh, T_in=T, T_out=T, C_in=Tp, N=hd, in0_bs=nh * T * Tp,
                                  in0_hs=T * Tp, ld_in0=Tp, w_bs=inner * Tp, w_hs=hd * Tp, ldw=Tp, out_bs=T * inner,
-                                 out_hs=hd, ld_out=inner))
+                                 out_hs=hd, ld_out=inner, precision=ops.attention_precision()))
             ol.append(conv(bufO, inner, T, t["o_w"], t["o_b"], X, C, T, [0], res=X, res_mode=RES_ADD, res_bs=T * C,
                            ld_res=C))
             ol.append(ops.layernorm_op(X, t["ln3_w"], t["ln3_b"], bufN, B * T, C))
@@ -859,7 +860,7 @@ class Serenade(_Packed):
             raise ValueError("Serenade.inference_ragged: no items")
         _require_cuda(items[0][0], "Serenade.inference_ragged")
         shapes = tuple((int(it[0].shape[0]), int(it[3].shape[0])) for it in items)
-        key = ("ragged", shapes, n_timesteps, ops.DEFAULT_PRECISION)
+        key = ("ragged", shapes, n_timesteps, ops.DEFAULT_PRECISION, ops.attention_precision())
         rp = _lru_get(self._plans, key, 4, lambda: RaggedInferencePlan(self, shapes, n_timesteps))
         rp.load(items)
         dev = items[0][0].device
@@ -868,7 +869,7 @@ class Serenade(_Packed):
         return rp.run(noises)
 
     def _inference_plan(self, B, T, Tr, n_timesteps):
-        key = (B, T, Tr, n_timesteps, ops.DEFAULT_PRECISION)
+        key = (B, T, Tr, n_timesteps, ops.DEFAULT_PRECISION, ops.attention_precision())
         return _lru_get(self._plans, key, 8, lambda: InferencePlan(self, B, T, Tr, n_timesteps))
 
     @torch.inference_mode()

@@ -16,6 +16,11 @@ from ._lib import (ACT_LEAKY, ACT_MISH, ACT_NONE, ACT_SILU, POST_DIV, POST_LEAKY
 
 
 DEFAULT_PRECISION = _lib.PREC_FP32  # contraction arithmetic of ops built without an explicit precision
+ATTENTION_PRECISION = None  # Q K^T / P V of the estimator's self-attention; None: DEFAULT_PRECISION
+
+
+def attention_precision():
+    return DEFAULT_PRECISION if ATTENTION_PRECISION is None else ATTENTION_PRECISION
 NO_HALO = False  # True: force the generic kernel everywhere (A/B timing)
 # Split-K for launches whose tile grid cannot fill the chip (B = 1 / short utterances; conv_splitk.hip): every ConvOp
 # is handed the per-device workspace below and the library decides per call.  SERENADE_AMD_SPLITK=0 turns it off.

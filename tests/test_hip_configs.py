@@ -139,6 +139,29 @@ def test_c5_long_form_share_of_one_gpu(dev, model, voc):
     assert (wave[0].cpu() - ref_wave).abs().max().item() < WAVE_ATOL
 
 
+def test_c5_mfma_attention_option(dev, model, voc, precision):
+    """configs[4]'s "MFMA attention": Q K^T and P V on the bf16 matrix cores (split-bf16, fp32 accumulate), every conv /
+    linear in exact fp32 -- holds the north star's gates at T = 4096 and differs from the all-fp32 run"""
+    if precision != "fp32":
+        pytest.skip("one arm: main precision fp32, attention precision switched")
+    B, Tn = 1, 4096
+    d = synth_inputs(4, Tn, T_ref=256, seed=1238)
+    one = {k: v[0:1] for k, v in d.items()}
+    ref_mel, ref_wave = oracle_chain("c5", one, 10)
+    plain = infer(model, one, dev, noise=one["z"])
+    for attn in ("bf16x3", "bf16x6"):
+        serenade_amd.set_attention_precision(attn)
+        try:
+            assert serenade_amd.get_attention_precision() == attn
+            mel = infer(model, one, dev, noise=one["z"])
+            wave = voc.decode_batch(mel.unsqueeze(0) if mel.dim() == 2 else mel)
+        finally:
+            serenade_amd.set_attention_precision(None)
+        assert mel.shape == plain.shape and not torch.equal(mel, plain)
+        assert nerr(mel.reshape(ref_mel.shape), ref_mel) < MEL_RTOL, attn
+        assert (wave.reshape(-1).cpu() - ref_wave.reshape(-1)).abs().max().item() < WAVE_ATOL, attn
+
+
 def test_reloading_weights_into_a_model_that_has_run(dev):
     """split-bf16 weight planes are cached per weight tensor; load_state_dict() copies into the live
     parameters (same address), so a stale cache would contract the new checkpoint with the old planes.  Run with
