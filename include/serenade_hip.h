@@ -223,28 +223,18 @@ int srn_hifigan_resunit(const SrnResUnitParams* p, void* stream);
 int srn_pd_gather(const float* x, const float* d, float* out, int B, int T, int C, float dilation, float slope,
                   void* stream);
 
-/* GST reference encoder layer: Conv2d(k3, s2, p1, no bias) + BatchNorm2d(eval) + ReLU (style_encoder.py:142-154),
- * NHWC: x (B, H, W, Ci) -> y (B, Ho, Wo, Co); w (Co, 3, 3, Ci); bn_scale/bn_shift (Co) = folded running stats. */
-int srn_conv2d_bn_relu(const float* x, const float* w, const float* bn_scale, const float* bn_shift, float* y, int B,
-                       int H, int W, int Ci, int Co, void* stream);
-
-/* torch.nn.GRU last hidden state (style_encoder.py:169,188-189): xs (B, T, I) -> h (B, H); gates r,z,n. */
-int srn_gru_last(const float* xs, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* h,
-                 int B, int T, int I, int H, void* stream);
-
-/* The same GRU with the input projection hoisted out: gi (B, T, 3H) = x W_ih^T + b_ih comes from one srn_conv_gemm
- * over all (b, t) rows; this call runs only the recurrence h -> W_hh h.  w_hh_t (H, 3H) = W_hh transposed. */
+/* GST style encoder (serenade/modules/gst/style_encoder.py:142-191,235-252).  Its Conv2d(k3, s2, p1) + BatchNorm2d(eval)
+ * + ReLU layers are srn_conv_gemm launches (one stride-2 three-tap contraction along the mel axis per kernel row, BatchNorm
+ * folded into the weights); the two entry points below are the tail. */
+/* torch.nn.GRU's last hidden state (style_encoder.py:169,188-189; gates r, z, n) with the input projection hoisted out:
+ * gi (B, T, 3H) = x W_ih^T + b_ih comes from one srn_conv_gemm over all (b, t) rows; this call runs only the recurrence
+ * h -> W_hh h.  w_hh_t (H, 3H) = W_hh transposed. */
 int srn_gru_recur_last(const float* gi, const float* w_hh_t, const float* b_hh, float* h, int B, int T, int H,
                        void* stream);
 
-/* StyleTokenLayer (style_encoder.py:235-252 + gst/attention.py:110-184,298-300): q (B, Dq) -> out (B, F).
- * embs (n_tok, dk_in) raw (tanh applied inside). */
-int srn_style_token_attention(const float* ref, const float* embs, const float* wq, const float* bq, const float* wk,
-                              const float* bk, const float* wv, const float* bv, const float* wo, const float* bo,
-                              float* out, int B, int Dq, int n_tok, int dk_in, int F, int n_head, void* stream);
-
-/* The same layer with its input-independent parts formed at weight-packing time: k, v (n_tok, F) =
- * tanh(embs) W_k^T + b_k / W_v^T + b_v; wq_t (Dq, F), wo_t (F, F) = W_q, W_out transposed. */
+/* StyleTokenLayer (style_encoder.py:235-252 + gst/attention.py:110-184,298-300): ref (B, Dq) -> out (B, F), with its
+ * input-independent parts formed at weight-packing time: k, v (n_tok, F) = tanh(embs) W_k^T + b_k / W_v^T + b_v;
+ * wq_t (Dq, F), wo_t (F, F) = W_q, W_out transposed. */
 int srn_style_token_attention_kv(const float* ref, const float* wq_t, const float* bq, const float* k, const float* v,
                                  const float* wo_t, const float* bo, float* out, int B, int Dq, int n_tok, int F,
                                  int n_head, void* stream);

@@ -108,9 +108,6 @@ _SIGS = {
     "srn_renorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "srn_out_conv_tanh": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "srn_pd_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
-    "srn_conv2d_bn_relu": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "srn_gru_last": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "srn_style_token_attention": (c_int, [_P] * 11 + [c_int] * 6 + [_P]),
     "srn_pad_signal": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_logmel": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, c_float, c_int, _P]),
     "srn_loudness": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P]),

@@ -743,7 +743,7 @@ class StyleEncoder(_Packed):
         # kh the op is a stride-2, 3-tap conv along W over input row 2*ho + kh - 1, batched over (b, ho).
         # Every layer input lives in a buffer with one zero row above and below (so kh = 0 / 2 never leave it);
         # the kh = 1 launch initialises the output (+ folded BN shift), kh = 0 accumulates, kh = 2 accumulates
-        # and applies the ReLU.  [The direct kernel srn_conv2d_bn_relu stays in the ABI; this is ~10x faster.]
+        # and applies the ReLU.
         H, W, Ci = T, self.idim, 1
         c0 = P["convs"][0]["cpad"]
         cur = torch.zeros(B, H + 2, W, c0, device=dev, dtype=torch.float32)
@@ -770,13 +770,12 @@ class StyleEncoder(_Packed):
         ref = torch.zeros(B, self.gru_units, device=dev, dtype=torch.float32)
         # GRU: input projection of all (b, t) rows as one contraction over the chip, then the short recurrence
         G3, I = 3 * self.gru_units, W * Ci
-        if I % 4 == 0:
-            gi = torch.zeros(B, H, G3, device=dev, dtype=torch.float32)
-            ol.append(ConvOp(in0=cur, w=P["w_ih"], out=gi, n_batch=1, T_in=B * H, T_out=B * H, C_in=I, N=G3, ld_in0=I,
-                             ldw=I, ld_out=G3, bias=P["b_ih"]))
-            ol.append(ops.gru_recur_last_op(gi, P["w_hh_t"], P["b_hh"], ref, B, H, self.gru_units))
-        else:
-            ol.append(ops.gru_last_op(cur, P["w_ih"], P["w_hh"], P["b_ih"], P["b_hh"], ref, B, H, I, self.gru_units))
+        if I % 4 != 0:
+            raise ValueError(f"GRU input width {I} (mel bins left x channels) must be a multiple of 4")
+        gi = torch.zeros(B, H, G3, device=dev, dtype=torch.float32)
+        ol.append(ConvOp(in0=cur, w=P["w_ih"], out=gi, n_batch=1, T_in=B * H, T_out=B * H, C_in=I, N=G3, ld_in0=I,
+                         ldw=I, ld_out=G3, bias=P["b_ih"]))
+        ol.append(ops.gru_recur_last_op(gi, P["w_hh_t"], P["b_hh"], ref, B, H, self.gru_units))
         ol.append(ops.style_token_attention_kv_op(ref, P["wq_t"], P["bq"], P["tok_k"], P["tok_v"], P["wo_t"], P["bo"],
                                                   out, B, self.gru_units, self.gst_tokens, self.gst_token_dim,
                                                   self.gst_heads))

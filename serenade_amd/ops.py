@@ -353,19 +353,6 @@ def pd_gather_op(x, d, out, B, T, C, dilation, slope):
     return CallOp("srn_pd_gather", (x, d, out, B, T, C, float(dilation), float(slope)))
 
 
-def conv2d_bn_relu_op(x, w, bn_scale, bn_shift, y, B, H, W, Ci, Co):
-    return CallOp("srn_conv2d_bn_relu", (x, w, bn_scale, bn_shift, y, B, H, W, Ci, Co))
-
-
-def gru_last_op(xs, w_ih, w_hh, b_ih, b_hh, h, B, T, I, H):
-    return CallOp("srn_gru_last", (xs, w_ih, w_hh, b_ih, b_hh, h, B, T, I, H))
-
-
-def style_token_attention_op(ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok, dk_in, F, n_head):
-    return CallOp("srn_style_token_attention", (ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok,
-                                                dk_in, F, n_head))
-
-
 def gru_recur_last_op(gi, w_hh_t, b_hh, h, B, T, H):
     return CallOp("srn_gru_recur_last", (gi, w_hh_t, b_hh, h, B, T, H))
 

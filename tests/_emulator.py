@@ -235,23 +235,6 @@ def emul_call(name, a):
         for k, idx in ((1, t - r), (2, t + r)):
             ok = ((idx >= 0) & (idx < T)).unsqueeze(-1)
             ov[:, :, k * C:(k + 1) * C] = torch.gather(xv, 1, idx.clamp(0, T - 1).unsqueeze(-1).expand(B, T, C)) * ok
-    elif name == "srn_conv2d_bn_relu":
-        x, w, sc, sh, y, B, H, W, Ci, Co = a
-        xv = _v(x, B * H * W * Ci).reshape(B, H, W, Ci).permute(0, 3, 1, 2)
-        o = F.conv2d(xv, w.permute(0, 3, 1, 2), None, stride=2, padding=1)
-        o = F.relu(o * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
-        _v(y, o.numel()).reshape(o.shape)[:] = o
-    elif name == "srn_gru_last":
-        xs, wih, whh, bih, bhh, h, B, T, I, H = a
-        xv = _v(xs, B * T * I).reshape(B, T, I)
-        hh = torch.zeros(B, H)
-        for t in range(T):
-            gi, gh = xv[:, t] @ wih.t() + bih, hh @ whh.t() + bhh
-            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
-            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
-            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
-            hh = (1 - z) * n + z * hh
-        _v(h, B * H).reshape(B, H)[:] = hh
     elif name == "srn_scatter_rows":
         src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C = a
         sv, dv = _v(src), _v(dst)
@@ -300,15 +283,6 @@ def emul_call(name, a):
         sc = torch.einsum("bhd,thd->bht", q.view(B, nh, dk), k.view(n_tok, nh, dk)) / math.sqrt(dk)
         ctx = torch.einsum("bht,thd->bhd", torch.softmax(sc, -1), v.view(n_tok, nh, dk)).reshape(B, Fd)
         _v(out, B * Fd).reshape(B, Fd)[:] = ctx @ wo_t + bo
-    elif name == "srn_style_token_attention":
-        ref, embs, wq, bq, wk, bk, wv, bv, wo, bo, out, B, Dq, n_tok, dk_in, Fd, nh = a
-        toks = torch.tanh(embs)
-        q = _v(ref, B * Dq).reshape(B, Dq) @ wq.t() + bq
-        k, v = toks @ wk.t() + bk, toks @ wv.t() + bv
-        dk = Fd // nh
-        sc = torch.einsum("bhd,thd->bht", q.view(B, nh, dk), k.view(n_tok, nh, dk)) / math.sqrt(dk)
-        ctx = torch.einsum("bht,thd->bhd", torch.softmax(sc, -1), v.view(n_tok, nh, dk)).reshape(B, Fd)
-        _v(out, B * Fd).reshape(B, Fd)[:] = ctx @ wo.t() + bo
     elif name == "srn_rowln_fwd":
         x, m, m_bs, a_, a_bs, y, B, T, C, eps = a
         xv = _v(x, B * T * C).reshape(B, T, C)

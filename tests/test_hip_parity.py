@@ -379,29 +379,7 @@ def test_norm_and_elementwise_kernels(dev):
 
 
 def test_gst_kernels(dev):
-    B, H, W = 2, 70, 80
-    x = rnd(B, H, W, 1, seed=48)
-    chans = (1, 128, 128, 256)
-    for i in range(3):
-        ci, co = chans[i], chans[i + 1]
-        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        w = rnd(co, 3, 3, ci, seed=49 + i) / np.sqrt(9 * ci)
-        y = torch.zeros(B, Ho, Wo, co)
-        e = _run_call(dev, "srn_conv2d_bn_relu", [x, w, 1 + 0.1 * rnd(co, seed=52), 0.1 * rnd(co, seed=53), y, B, H, W,
-                                                  ci, co])
-        assert e < KTOL.k
-        x = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), stride=2, padding=1)).permute(0, 2, 3, 1)
-        x = x.contiguous()
-        H, W = Ho, Wo
-    e = _run_call(dev, "srn_gru_last", [rnd(2, 3, 1024, seed=54), rnd(384, 1024, seed=55) / 32, rnd(384, 128, seed=56) / 11,
-                                        0.1 * rnd(384, seed=57), 0.1 * rnd(384, seed=58), torch.zeros(2, 128), 2, 3,
-                                        1024, 128])
-    assert e < KTOL.k
-    a = [rnd(2, 128, seed=59), 0.5 * rnd(50, 64, seed=60), rnd(256, 128, seed=61) / 11, 0.1 * rnd(256, seed=62),
-         rnd(256, 64, seed=63) / 8, 0.1 * rnd(256, seed=64), rnd(256, 64, seed=65) / 8, 0.1 * rnd(256, seed=66),
-         rnd(256, 256, seed=67) / 16, 0.1 * rnd(256, seed=68), torch.zeros(2, 256), 2, 128, 50, 64, 256, 4]
-    assert _run_call(dev, "srn_style_token_attention", a) < KTOL.k
-    # round-2 forms: recurrence on a precomputed input projection, attention on precomputed K / V
+    # recurrence on a precomputed input projection, attention on precomputed K / V
     e = _run_call(dev, "srn_gru_recur_last", [rnd(3, 5, 384, seed=70), rnd(128, 384, seed=71) / 11,
                                               0.1 * rnd(384, seed=72), torch.zeros(3, 128), 3, 5, 128])
     assert e < KTOL.k
