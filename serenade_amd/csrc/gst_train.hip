@@ -19,6 +19,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
 // rows per partial-sum chunk: at most ~256 chunks, so the finishing kernel's ordered sum stays short
 __host__ __device__ inline int64_t bn_rows_per_chunk(int64_t R) { return R <= 256 * 16 ? 16 : (R + 255) / 256; }
+// (bn_partial_kernel: one thread per channel walks a chunk's rows; bn_finish_kernel adds the chunks)
 
 // mode 0: partial[chunk][0][c] = sum x, [1][c] = sum x^2
 // mode 1: g = dy * (y > 0): [0][c] = sum g, [1][c] = sum g * xhat,  xhat = (x - mean) * rstd
@@ -48,19 +49,28 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
 }
 
-// sums the chunks in order.  mode 0: stats = (mean, rstd) with the biased batch variance, running statistics updated
-// like nn.BatchNorm2d (momentum, unbiased variance).  mode 1: out = (sum g, sum g xhat) = (dbeta, dgamma).
+// sums the chunks in a fixed order (four interleaved runs per channel, combined 0..3).  mode 0: stats = (mean, rstd) with
+// the biased batch variance, running statistics updated like nn.BatchNorm2d (momentum, unbiased variance).
+// mode 1: out = (sum g, sum g xhat) = (dbeta, dgamma).  64 channels x 4 runs per workgroup.
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
                                                         int n_chunk, int64_t R, int C, float eps, float momentum,
                                                         int mode) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[2][4][64];
+  const int lc = threadIdx.x & 63, run = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < n_chunk; ++k) {
-    s0 += partial[((int64_t)k * 2) * C + c];
-    s1 += partial[((int64_t)k * 2 + 1) * C + c];
-  }
+  if (c < C)
+    for (int k = run; k < n_chunk; k += 4) {
+      s0 += partial[((int64_t)k * 2) * C + c];
+      s1 += partial[((int64_t)k * 2 + 1) * C + c];
+    }
+  red[0][run][lc] = s0;
+  red[1][run][lc] = s1;
+  __syncthreads();
+  if (run != 0 || c >= C) return;
+  s0 = (red[0][0][lc] + red[0][1][lc]) + (red[0][2][lc] + red[0][3][lc]);
+  s1 = (red[1][0][lc] + red[1][1][lc]) + (red[1][2][lc] + red[1][3][lc]);
   if (mode == 0) {
     const double mean_d = (double)s0 / (double)R;
     const float mean = (float)mean_d;
@@ -341,8 +351,8 @@ extern "C" int srn_bn_relu_fwd(const float* x, const float* gamma, const float* 
   const unsigned cb = (unsigned)((C + 255) / 256);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, chunks), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3(cb), dim3(256), 0, st, (const float*)partial, stats, run_mean, run_var,
-                     chunks, rows, C, eps, momentum, 0);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, (const float*)partial, stats,
+                     run_mean, run_var, chunks, rows, C, eps, momentum, 0);
   const int64_t n4 = rows * C / 4;
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
@@ -360,8 +370,8 @@ extern "C" int srn_bn_relu_bwd(const float* x, const float* y, const float* dy, 
   hipStream_t st = (hipStream_t)stream;
   const unsigned cb = (unsigned)((C + 255) / 256);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, chunks), dim3(256), 0, st, x, y, dy, stats, partial, rows, C, 1);
-  hipLaunchKernelGGL(bn_finish_kernel, dim3(cb), dim3(256), 0, st, (const float*)partial, sums, (float*)nullptr,
-                     (float*)nullptr, chunks, rows, C, 0.f, 0.f, 1);
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, (const float*)partial, sums,
+                     (float*)nullptr, (float*)nullptr, chunks, rows, C, 0.f, 0.f, 1);
   const int64_t n4 = rows * C / 4;
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, st, x, y, dy, stats, (const float*)sums, gamma,

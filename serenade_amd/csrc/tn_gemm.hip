@@ -163,8 +163,11 @@ int plan_split(const SrnTnGemmParams& p, int& k_per) {
   const int64_t K = (int64_t)p.n_items * p.T_a;
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.n_shifts * p.n_batch * p.n_head;
   int ks = 1;
-  if (tiles < 384) {  // ~3 workgroups per CU wanted; never fewer than 8 slabs per slice
-    ks = (int)((768 + tiles - 1) / tiles);
+  // ~3 workgroups per CU wanted, never fewer than 8 slabs per slice.  Swept on the training step's shapes
+  // (tools/tnbench.py, B = 4 x L = 1024): targets 256 / 384 / 512 / 768 / 1024 give 57 / 67 / 75 / 79 / 77 TFLOP/s overall
+  constexpr int target = 768;
+  if (tiles < target / 2) {
+    ks = (int)((target + tiles - 1) / tiles);
     const int64_t cap = K / (8 * BK);
     if (ks > cap) ks = (int)cap;
     if (ks > MAX_SPLIT) ks = MAX_SPLIT;
