@@ -86,6 +86,15 @@ def build_parser():
     p.add_argument("--batch-utterances", type=int, default=1,
                    help="(MI355X build only) convert this many source utterances, with all their styles, per exact "
                         "ragged batch (implies --batch-styles); outputs equal the one-by-one loop")
+    p.add_argument("--sifigan-checkpoint", type=str, default=None,
+                   help="(MI355X build only) also run the recipe's stage 9 in this process: re-analyse every converted "
+                        "waveform on the GPU (serenade_amd.world.Analyzer) and write NAME_sifigan.wav from this SiFiGAN "
+                        "generator checkpoint -- the same samples `serenade-postprocessing` would write from the wav "
+                        "and lf0 files, without the round trip through them")
+    p.add_argument("--sifigan-stats", type=str, default=None,
+                   help="joblib file with the `mcep` / `bap` scalers of the SiFiGAN model (with --sifigan-checkpoint)")
+    p.add_argument("--sifigan-noise-amp", type=float, default=0.003,
+                   help="noise_amp of ssc_postprocessing.yaml (with --sifigan-checkpoint)")
     return p
 
 
@@ -138,6 +147,18 @@ class DecodeJob:
         logging.info(f"model weights: {args.checkpoint}")
         self.sr = self.config["sampling_rate"]
         self.ext = os.path.splitext(self.dataset.audio_files[0])[1].lstrip(".")
+        self.post = None
+        if args.sifigan_checkpoint is not None:
+            if args.sifigan_stats is None:
+                raise ValueError("--sifigan-checkpoint needs --sifigan-stats")
+            from serenade_amd.bin.ssc_postprocessing import DEFAULTS
+            from serenade_amd import sifigan, world
+            gen = sifigan.SiFiGANGenerator(**DEFAULTS["generator"])
+            gen.load_state_dict(torch.load(args.sifigan_checkpoint, map_location="cpu")["model"]["generator"])
+            gen.remove_weight_norm()
+            self.post = (world.Analyzer(sample_rate=self.sr, scaler=load(args.sifigan_stats), pcm16=True,
+                                        noise_amp=args.sifigan_noise_amp),
+                         gen.eval().to(self.device))
 
     # ---- tensors -------------------------------------------------------------------------------------------
     def _t(self, a):
@@ -214,6 +235,15 @@ class DecodeJob:
         for (utt, style, x, _, _, _, lf0), wave in zip(jobs, waves):
             write_feats(os.path.join(out, f"{utt}_{style}.{self.ext}"), "lf0", lf0)
             write_wav_pcm16(os.path.join(out, f"{utt}_{style}.wav"), wave.cpu().numpy(), self.sr)
+            if self.post is not None:  # stage 9 without leaving the GPU: waveform -> WORLD features -> SiFiGAN
+                analyzer, gen = self.post
+                w = wave.reshape(1, -1).to(torch.float32)
+                in_signal, c, dfs, feats = analyzer(w, [w.size(1)], [np.asarray(lf0)])
+                if int(feats["ok"][0]):
+                    y = gen(in_signal, c, dfs)[0]
+                    write_wav_pcm16(os.path.join(out, f"{utt}_{style}_sifigan.wav"), y.view(-1).cpu().numpy(), self.sr)
+                else:
+                    logging.warning(f"{utt}_{style}: all of the f0 values are 0, no SiFiGAN output")
             done += x.shape[1]
         return done
 

@@ -201,6 +201,36 @@ def test_decode_cli_end_to_end_gpu(tmp_path):
     _cli_case(tmp_path, on_gpu=True)
 
 
+@pytest.mark.gpu
+def test_decode_cli_in_process_stage9_equals_the_two_cli_chain(tmp_path):
+    """--sifigan-checkpoint: mel -> HiFi-GAN -> WORLD analysis -> SiFiGAN in one process on the GPU writes the samples
+    the file-based chain (serenade-decode, then serenade-postprocessing on its wav + lf0 files) writes"""
+    from joblib import dump
+    from sklearn.preprocessing import StandardScaler
+    from serenade_amd import sifigan
+    from serenade_amd.bin import ssc_postprocessing
+    argv = _two_style_tree(tmp_path)
+    rng = np.random.default_rng(3)
+    dump({"mcep": StandardScaler().fit(rng.standard_normal((40, 40)) - 2), "bap": StandardScaler().fit(rng.standard_normal((40, 3)) * 9 - 10)},
+         tmp_path / "sifigan_stats.joblib")
+    gsd = fill_state_dict(_shapes.as_meta(sifigan.sifigan_shapes(**sifigan.DEFAULT_PARAMS)), seed=6)
+    torch.save({"model": {"generator": gsd}}, tmp_path / "sifigan.pkl")
+    torch.manual_seed(7)
+    ssc_decode.main(argv + ["--outdir", str(tmp_path / "one"), "--sifigan-checkpoint", str(tmp_path / "sifigan.pkl"),
+                            "--sifigan-stats", str(tmp_path / "sifigan_stats.joblib"), "--sifigan-noise-amp", "0"])
+    torch.manual_seed(7)
+    ssc_decode.main(argv + ["--outdir", str(tmp_path / "two")])
+    ssc_postprocessing.main(["generator=sifigan", f"in_dir={tmp_path / 'two'}", f"stats={tmp_path / 'sifigan_stats.joblib'}",
+                             f"checkpoint_path={tmp_path / 'sifigan.pkl'}", "noise_amp=0"])
+    names = sorted(n for n in os.listdir(tmp_path / "one") if n.endswith("_sifigan.wav"))
+    assert len(names) == 4 and names == sorted(n for n in os.listdir(tmp_path / "two") if n.endswith("_sifigan.wav"))
+    for n in names:
+        with wavmod.open(str(tmp_path / "one" / n)) as fa, wavmod.open(str(tmp_path / "two" / n)) as fb:
+            pa = np.frombuffer(fa.readframes(fa.getnframes()), dtype="<i2").astype(np.int32)
+            pb = np.frombuffer(fb.readframes(fb.getnframes()), dtype="<i2").astype(np.int32)
+        assert pa.shape == pb.shape and pa.size > 0 and np.abs(pa - pb).max() <= 1, n
+
+
 def test_cli_rejects_bad_argument_combinations(tmp_path):
     with pytest.raises(SystemExit):
         ssc_decode.main(["--outdir", str(tmp_path)])  # --stats / --checkpoint are required
