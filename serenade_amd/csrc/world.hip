@@ -16,9 +16,10 @@
 
 namespace {
 
-// threads per frame (template parameter NT of the frame kernels): CheapTrick 256 (three short transforms, 48 KB of
-// LDS, three frames per CU), D4C 512 (107 KB: one frame per CU, so its eight waves are all the latency hiding there
-// is -- measured 8.0 -> 6.0 ms per 16 392 frames against 256)
+// threads per frame (template parameter NT of the frame kernels): CheapTrick 256 (three short transforms, 33 KB of
+// LDS), D4C 512 (74 KB: two frames per CU -- the frame kernels are chains of short barrier-separated passes, so what
+// hides their latencies is the other frame on the CU; 256 -> 512 threads at one frame per CU measured 8.0 -> 5.9 ms
+// per 16 392 frames)
 constexpr int NT_CHEAPTRICK = 256, NT_D4C = 512, NT_F0 = 256;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kSafeGuard = 1e-12;                        // world::kMySafeGuardMinimum
@@ -41,7 +42,8 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // In-place radix-2 decimation-in-time FFT of N = 2^LOG2N complex points held as two LDS planes.  Input in
-// bit-reversed order, output in natural order; tw = N/2 pairs (cos, -sin)(2 pi m / N) in LDS.
+// bit-reversed order, output in natural order; tw = the first N/4 pairs (cos, -sin)(2 pi m / N) in LDS: the second
+// quarter of the half circle is w[m + N/4] = -i w[m] = (w.im, -w.re), which keeps the table at N/2 doubles.
 template <int LOG2N, int NT>
 __device__ void fft_lds(double* re, double* im, const double* tw) {
   constexpr int N = 1 << LOG2N;
@@ -54,7 +56,11 @@ __device__ void fft_lds(double* re, double* im, const double* tw) {
       const int k = b & (half - 1);
       const int i = ((b >> (s - 1)) << s) + k;
       const int j = i + half;
-      const double wr = tw[2 * k * tstep], wi = tw[2 * k * tstep + 1];
+      int m = k * tstep;
+      const bool upper = m >= N / 4;
+      m -= upper ? N / 4 : 0;
+      const double t0 = tw[2 * m], t1 = tw[2 * m + 1];
+      const double wr = upper ? t1 : t0, wi = upper ? -t0 : t1;
       const double xr = re[j], xi = im[j];
       const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
       const double ur = re[i], ui = im[i];
@@ -75,18 +81,22 @@ enum { WIN_CHEAPTRICK = 0, WIN_HANNING = 1, WIN_BLACKMAN = 2 };
 // F0-adaptive windowing (cheaptrick.cpp / d4c.cpp GetWindowedWaveform): gathers 2*hwl+1 samples around `position`
 // (edge samples repeated), applies the window, removes the window-weighted mean, optionally scales to unit energy,
 // and leaves the frame in (re, im) in bit-reversed order -- im = (n + 1) * re when `ramp` (D4C's centroid transforms
-// the frame and its time-weighted copy; both ride in ONE complex FFT), else 0.  scr: 2N doubles of scratch.
-// Returns the number of windowed samples, or 0 when unit energy was requested on an all-zero frame.
+// the frame and its time-weighted copy; both ride in ONE complex FFT), else 0.  Scratch: scr[0..N) holds the window,
+// the im plane the products on the way (natural order); the final values pass through registers on their way to
+// the bit-reversed positions.  Returns the number of windowed samples, or 0 when unit energy was requested on an
+// all-zero frame.
 template <int LOG2N, int NT>
 __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, double f0, double position, int kind,
                               double ratio, bool unit_energy, bool ramp, double* re, double* im, double* scr,
                               double* red) {
   constexpr int N = 1 << LOG2N;
+  constexpr int NI = (N + NT - 1) / NT;
   int hwl = kind == WIN_CHEAPTRICK ? mround(1.5 * fs / f0) : mround(ratio * fs / f0 / 2.0);
   hwl = clampi(hwl, 0, (N - 1) / 2);
   const int n = 2 * hwl + 1;
   const int origin = mround(position * fs + 0.001);
   double ww = 0.0;
+  __syncthreads();  // the planes may still be read by the caller's previous step
   for (int j = threadIdx.x; j < n; j += NT) {
     const int base = j - hwl;
     double w;
@@ -99,28 +109,30 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
       w = kind == WIN_HANNING ? 0.5 * c1 + 0.5 : 0.42 + 0.5 * c1 + 0.08 * cos(kPi * pos * f0 * 2);
     }
     scr[j] = w;
-    scr[N + j] = x[clampi(origin + base, 0, x_len - 1)];
+    im[j] = x[clampi(origin + base, 0, x_len - 1)];
     ww += w * w;
   }
   double wnorm = 1.0;  // CheapTrick's window has unit energy; D4C's windows are used as they are
   if (kind == WIN_CHEAPTRICK) wnorm = sqrt(block_sum<NT>(ww, red));
   double sw = 0.0, sxw = 0.0;
-  for (int j = threadIdx.x; j < n; j += NT) {
+  for (int j = threadIdx.x; j < n; j += NT) {  // every thread revisits its own j: no barrier needed in between
     const double w = scr[j] / wnorm;
     scr[j] = w;
-    const double v = scr[N + j] * w;
-    scr[N + j] = v;
+    const double v = im[j] * w;
+    im[j] = v;
     sw += w;
     sxw += v;
   }
   sw = block_sum<NT>(sw, red);
   sxw = block_sum<NT>(sxw, red);
   const double coef = sxw / sw;
+  double vals[NI];
   double pw = 0.0;
-  for (int j = threadIdx.x; j < n; j += NT) {
-    const double v = scr[N + j] - scr[j] * coef;
-    scr[N + j] = v;
-    pw += v * v;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = threadIdx.x + i * NT;
+    vals[i] = j < n ? im[j] - scr[j] * coef : 0.0;
+    pw += vals[i] * vals[i];
   }
   double escale = 1.0;
   if (unit_energy) {
@@ -128,13 +140,16 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
     if (!(pw > 0.0)) return 0;
     escale = sqrt(pw);
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < N; j += NT) {
-    double v = 0.0;
-    if (j < n) v = unit_energy ? scr[N + j] / escale : scr[N + j];
-    const int r = brev<LOG2N>(j);
-    re[r] = v;
-    im[r] = ramp ? v * (j + 1.0) : 0.0;
+  __syncthreads();  // all natural-order reads of im are done
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = threadIdx.x + i * NT;
+    if (j < N) {
+      const double v = unit_energy ? vals[i] / escale : vals[i];
+      const int r = brev<LOG2N>(j);
+      re[r] = v;
+      im[r] = ramp ? v * (j + 1.0) : 0.0;
+    }
   }
   return n;  // fft_lds starts with a barrier
 }
@@ -195,7 +210,7 @@ template <int NT>
 __device__ void linear_smoothing(const double* in, double* out, int half, double width, int fs, int N, double add,
                                  double* scr, double* red) {
   int boundary = (int)(width * N / fs) + 1;
-  boundary = clampi(boundary, 1, half);
+  boundary = clampi(boundary, 1, N / 4 + 1);  // width <= F0 <= fs / 4 (the kernels clamp F0): M <= N + 4 fits scr
   const int M = half + 2 * boundary + 1;
   const double step = (double)fs / N;
   __syncthreads();
@@ -241,7 +256,7 @@ __device__ __forceinline__ Frame load_frame(const SrnWorldParams& p) {
 template <int LOG2N, int NT>
 __device__ __forceinline__ void load_twiddles(const double* __restrict__ g, double* tw) {
   constexpr int N = 1 << LOG2N;
-  for (int i = threadIdx.x; i < N; i += NT) tw[i] = g[i];
+  for (int i = threadIdx.x; i < N / 2; i += NT) tw[i] = g[i];  // the first quarter of the host's N/2-pair table
 }
 
 // ------------------------------------------------------------------------------------------------ CheapTrick
@@ -251,9 +266,9 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
   extern __shared__ __attribute__((aligned(16))) double lds_w[];
   double* re = lds_w;            // N
   double* im = re + N;           // N
-  double* tw = im + N;           // N   (N/2 pairs)
-  double* scr = tw + N;          // 2N
-  double* pw = scr + 2 * N;      // HALF + 1
+  double* tw = im + N;           // N / 2 (quarter-wave table)
+  double* scr = tw + N / 2;      // N + 8
+  double* pw = scr + N + 8;      // HALF + 1
   double* red = pw + HALF + 1;   // 2 NT / 64
   const Frame fr = load_frame(p);
   if (!fr.valid) return;
@@ -328,16 +343,15 @@ __device__ void bitonic_sort(double* a, int n) {
 }
 
 template <int LOG2N, int NT>
-__global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
+__global__ __launch_bounds__(NT, 2) void d4c_kernel(const SrnWorldParams p) {
   constexpr int N = 1 << LOG2N, HALF = N / 2;
   extern __shared__ __attribute__((aligned(16))) double lds_w[];
   double* re = lds_w;
   double* im = re + N;
-  double* tw = im + N;
-  double* scr = tw + N;            // 2N
-  double* cen = scr + 2 * N;       // HALF + 1
-  double* pw = cen + HALF + 1;     // HALF + 1
-  double* gd = pw + HALF + 1;      // HALF + 1
+  double* tw = im + N;             // N / 2 (quarter-wave table)
+  double* scr = tw + N / 2;        // N + 8
+  double* pw = scr + N + 8;        // HALF + 1
+  double* gd = pw + HALF + 1;      // HALF + 1: centroid, then group delay
   double* red = gd + HALF + 1;     // 2 NT / 64
   constexpr int NW = NT / 64;
   __shared__ int s_arg;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
   f0 = fmax(f0, 47.0);  // world::kFloorF0D4C
 
   // ---- static centroid: two frames a quarter period before / after, energy-normalised, Blackman of 4 periods
-  for (int k = threadIdx.x; k <= HALF; k += NT) cen[k] = 0.0;
+  for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] = 0.0;
   for (int side = 0; side < 2; ++side) {
     const double pos = fr.t + (side == 0 ? -0.25 : 0.25) / f0;
     const int n = windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, pos, WIN_BLACKMAN, 4.0, true, true, re, im, scr, red);
@@ -392,11 +406,11 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
       const double s1r = 0.5 * (zr + cr), s1i = 0.5 * (zi + ci);
       const double dr = zr - cr, di = zi - ci;
       const double s2r = 0.5 * di, s2i = -0.5 * dr;
-      cen[k] += s2r * s1r + s1i * s2i;
+      gd[k] += s2r * s1r + s1i * s2i;
     }
     __syncthreads();
   }
-  dc_correction<NT>(cen, HALF, f0, fs, N, scr);
+  dc_correction<NT>(gd, HALF, f0, fs, N, scr);
 
   // ---- smoothed power spectrum: Hanning window of 4 periods, DC correction, smoothing over one F0
   windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, fr.t, WIN_HANNING, 4.0, false, false, re, im, scr, red);
@@ -406,10 +420,10 @@ __global__ __launch_bounds__(NT) void d4c_kernel(const SrnWorldParams p) {
   linear_smoothing<NT>(pw, pw, HALF, f0, fs, N, 0.0, scr, red);
 
   // ---- static group delay minus its own smoothed version
-  for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] = cen[k] / pw[k];
+  for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] = gd[k] / pw[k];
   linear_smoothing<NT>(gd, gd, HALF, f0 / 2.0, fs, N, 0.0, scr, red);
-  linear_smoothing<NT>(gd, cen, HALF, f0, fs, N, 0.0, scr, red);
-  for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] -= cen[k];
+  linear_smoothing<NT>(gd, pw, HALF, f0, fs, N, 0.0, scr, red);  // the power spectrum is spent: its plane takes this
+  for (int k = threadIdx.x; k <= HALF; k += NT) gd[k] -= pw[k];
   __syncthreads();
 
   // ---- per band: Nuttall-windowed group delay -> power spectrum -> share of everything but the `boundary`+1
@@ -709,8 +723,8 @@ __global__ void excitation_kernel(ExcArgs a, int64_t bs, const int* __restrict__
   }
 }
 
-int world_lds_bytes(int N, int planes_half, int nt) {
-  return (int)sizeof(double) * (5 * N + planes_half * (N / 2 + 1) + 2 * (nt / 64));
+int world_lds_bytes(int N, int planes_half, int nt) {  // re, im | quarter-wave twiddles | scratch | planes | reductions
+  return (int)sizeof(double) * (2 * N + N / 2 + (N + 8) + planes_half * (N / 2 + 1) + 2 * (nt / 64));
 }
 
 int check_world(const SrnWorldParams* p, const char* who) {
@@ -782,7 +796,7 @@ extern "C" int srn_world_d4c(const SrnWorldParams* p, void* stream) {
   dim3 grid(p->max_frames, p->n_batch);
   hipStream_t st = (hipStream_t)stream;
   static SrnSmemAttr a10, a11;
-  const int lds = world_lds_bytes(N, 3, NT_D4C);
+  const int lds = world_lds_bytes(N, 2, NT_D4C);
   if (N == 1024) {
     if (int rc = a10.ensure((const void*)(d4c_kernel<10, NT_D4C>), lds)) return rc;
     hipLaunchKernelGGL((d4c_kernel<10, NT_D4C>), grid, dim3(NT_D4C), lds, st, *p);
