@@ -9,7 +9,8 @@
 // Design: WORLD is float64 and ratio-of-small-differences arithmetic (group delay minus its smoothed self, sorted
 // band powers 60 dB apart), so everything runs in fp64 -- the MI355X issues fp64 FMAs at the fp32 rate.  ONE
 // workgroup analyses ONE frame and never leaves the CU: the F0-adaptive window is applied while gathering the
-// frame's samples from the (L2-resident) waveform, the radix-2 FFT runs in LDS (SoA planes, twiddles in LDS), power
+// frame's samples from the (L2-resident) waveform, the radix-2 FFT runs in LDS (SoA planes, twiddles in LDS; real
+// data through a half-length complex transform), power
 // spectrum / DC correction / rectangular smoothing (a block prefix sum) / cepstral lifter / bitonic sort of the band
 // powers all work on LDS arrays, and only 513 (cepstrum) or 3 (band aperiodicity) doubles per frame go back to HBM.
 #include "common.h"
@@ -20,7 +21,7 @@ namespace {
 // LDS), D4C 512 (74 KB: two frames per CU -- the frame kernels are chains of short barrier-separated passes, so what
 // hides their latencies is the other frame on the CU; 256 -> 512 threads at one frame per CU measured 8.0 -> 5.9 ms
 // per 16 392 frames)
-constexpr int NT_CHEAPTRICK = 256, NT_D4C = 512, NT_F0 = 256;
+constexpr int NT_CHEAPTRICK = 256, NT_D4C = 512 /* at N = 2048; N / 4 in general */, NT_F0 = 256;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kSafeGuard = 1e-12;                        // world::kMySafeGuardMinimum
 constexpr double kNoiseAfterSmoothing = 1.7716279188122702e-16;  // world::kEps * sqrt(2 / pi): E|randn| * eps
@@ -41,26 +42,35 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
-// In-place radix-2 decimation-in-time FFT of N = 2^LOG2N complex points held as two LDS planes.  Input in
-// bit-reversed order, output in natural order; tw = the first N/4 pairs (cos, -sin)(2 pi m / N) in LDS: the second
-// quarter of the half circle is w[m + N/4] = -i w[m] = (w.im, -w.re), which keeps the table at N/2 doubles.
-template <int LOG2N, int NT>
+// (cos, -sin)(2 pi m / N) for m < N / 2 from the quarter-wave table tw (N / 4 pairs): the second quarter of the half
+// circle is w[m + N/4] = -i w[m] = (w.im, -w.re), which keeps the table at N / 2 doubles of LDS.
+template <int LOG2N>
+__device__ __forceinline__ void twiddle(const double* tw, int m, double& wr, double& wi) {
+  constexpr int Q = (1 << LOG2N) / 4;
+  const bool upper = m >= Q;
+  m -= upper ? Q : 0;
+  const double t0 = tw[2 * m], t1 = tw[2 * m + 1];
+  wr = upper ? t1 : t0;
+  wi = upper ? -t0 : t1;
+}
+
+// In-place radix-2 decimation-in-time FFT of M = 2^LOG2M complex points held as two LDS planes.  Input in
+// bit-reversed order, output in natural order.  tw is the quarter-wave table of N = M << TWSHIFT points (an M-point
+// transform walks it in steps of 2^TWSHIFT).
+template <int LOG2M, int NT, int TWSHIFT = 0>
 __device__ void fft_lds(double* re, double* im, const double* tw) {
-  constexpr int N = 1 << LOG2N;
+  constexpr int M = 1 << LOG2M;
 #pragma unroll 1
-  for (int s = 1; s <= LOG2N; ++s) {
+  for (int s = 1; s <= LOG2M; ++s) {
     const int half = 1 << (s - 1);
-    const int tstep = N >> s;
+    const int tstep = M >> s;
     __syncthreads();
-    for (int b = threadIdx.x; b < N / 2; b += NT) {
+    for (int b = threadIdx.x; b < M / 2; b += NT) {
       const int k = b & (half - 1);
       const int i = ((b >> (s - 1)) << s) + k;
       const int j = i + half;
-      int m = k * tstep;
-      const bool upper = m >= N / 4;
-      m -= upper ? N / 4 : 0;
-      const double t0 = tw[2 * m], t1 = tw[2 * m + 1];
-      const double wr = upper ? t1 : t0, wi = upper ? -t0 : t1;
+      double wr, wi;
+      twiddle<LOG2M + TWSHIFT>(tw, (k * tstep) << TWSHIFT, wr, wi);
       const double xr = re[j], xi = im[j];
       const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
       const double ur = re[i], ui = im[i];
@@ -76,12 +86,40 @@ __device__ void fft_lds(double* re, double* im, const double* tw) {
 template <int LOG2N>
 __device__ __forceinline__ int brev(int n) { return (int)(__brev((unsigned)n) >> (32 - LOG2N)); }
 
+// Transform of N = 2^LOG2N REAL samples x at half the cost: z[m] = x[2m] + i x[2m+1] goes through an N/2-point complex
+// transform, one more pass separates X[k] = E[k] + w_N^k O[k], k = 0 .. N/2 (E, O: transforms of the even / odd
+// samples, recovered from Z[k] and conj Z[N/2 - k]).  The caller stores sample j at rfft_slot(j): plane (j & 1),
+// position bit-reversed over N/2.  Five of D4C's seven transforms and all three of CheapTrick's are of real data.
+template <int LOG2N>
+__device__ __forceinline__ int rfft_slot(int j) { return brev<LOG2N - 1>(j >> 1); }
+
+template <int LOG2N, int NT>
+__device__ void rfft_lds(double* re, double* im, const double* tw) {
+  constexpr int M = 1 << (LOG2N - 1);
+  fft_lds<LOG2N - 1, NT, 1>(re, im, tw);
+  for (int k = threadIdx.x; k <= M / 2; k += NT) {
+    const int kk = (M - k) & (M - 1);
+    const double ar = re[k], ai = im[k], br = re[kk], bi = im[kk];
+    const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+    const double orr = 0.5 * (ai + bi), oi = -0.5 * (ar - br);
+    double wr, wi;
+    twiddle<LOG2N>(tw, k, wr, wi);
+    const double pr = wr * orr - wi * oi, pi = wr * oi + wi * orr;
+    re[k] = er + pr;
+    im[k] = ei + pi;
+    re[M - k] = er - pr;      // X[N/2 - k] = conj(E[k] - w^k O[k])
+    im[M - k] = -(ei - pi);
+  }
+  __syncthreads();
+}
+
 enum { WIN_CHEAPTRICK = 0, WIN_HANNING = 1, WIN_BLACKMAN = 2 };
 
 // F0-adaptive windowing (cheaptrick.cpp / d4c.cpp GetWindowedWaveform): gathers 2*hwl+1 samples around `position`
 // (edge samples repeated), applies the window, removes the window-weighted mean, optionally scales to unit energy,
-// and leaves the frame in (re, im) in bit-reversed order -- im = (n + 1) * re when `ramp` (D4C's centroid transforms
-// the frame and its time-weighted copy; both ride in ONE complex FFT), else 0.  Scratch: scr[0..N) holds the window,
+// and leaves the frame ready for its transform: with `ramp` (D4C's centroid) re = frame, im = (n + 1) * frame in
+// bit-reversed order -- the frame and its time-weighted copy ride in ONE complex FFT (fft_lds); without, the real
+// frame packed for rfft_lds.  Scratch: scr[0..N) holds the window,
 // the im plane the products on the way (natural order); the final values pass through registers on their way to
 // the bit-reversed positions.  Returns the number of windowed samples, or 0 when unit energy was requested on an
 // all-zero frame.
@@ -146,12 +184,16 @@ __device__ int windowed_frame(const double* __restrict__ x, int x_len, int fs, d
     const int j = threadIdx.x + i * NT;
     if (j < N) {
       const double v = unit_energy ? vals[i] / escale : vals[i];
-      const int r = brev<LOG2N>(j);
-      re[r] = v;
-      im[r] = ramp ? v * (j + 1.0) : 0.0;
+      if (ramp) {  // complex transform of (frame, time-weighted frame)
+        const int r = brev<LOG2N>(j);
+        re[r] = v;
+        im[r] = v * (j + 1.0);
+      } else {  // real transform (rfft_lds)
+        ((j & 1) ? im : re)[rfft_slot<LOG2N>(j)] = v;
+      }
     }
   }
-  return n;  // fft_lds starts with a barrier
+  return n;  // the transforms start with a barrier
 }
 
 // interp1Q (common.cpp): y on the grid x0 + shift * k, linear, y's last difference taken as 0.
@@ -278,7 +320,7 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
   double f0 = fr.f0 <= p.f0_floor ? 500.0 : fr.f0;
   if (!(f0 < 0.25 * fs)) f0 = 0.25 * fs;
   const int n = windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, fr.t, WIN_CHEAPTRICK, 0.0, false, false, re, im, scr, red);
-  fft_lds<LOG2N, NT>(re, im, tw);
+  rfft_lds<LOG2N, NT>(re, im, tw);
   // power spectrum (+ the expected power of WORLD's 1e-12 * randn() safeguard) with DC correction
   const double floor_power = n * kSafeGuard * kSafeGuard;
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = re[k] * re[k] + im[k] * im[k] + floor_power;
@@ -287,12 +329,8 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
   // cepstrum of the symmetric log spectrum
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = log(pw[k]);
   __syncthreads();
-  for (int j = threadIdx.x; j < N; j += NT) {
-    const int r = brev<LOG2N>(j);
-    re[r] = pw[j <= HALF ? j : N - j];
-    im[r] = 0.0;
-  }
-  fft_lds<LOG2N, NT>(re, im, tw);
+  for (int j = threadIdx.x; j < N; j += NT) ((j & 1) ? im : re)[rfft_slot<LOG2N>(j)] = pw[j <= HALF ? j : N - j];
+  rfft_lds<LOG2N, NT>(re, im, tw);
   // smoothing lifter sinc(f0 q) and compensation lifter (1 - 2 q1) + 2 q1 cos(2 pi f0 q), then / N
   const double q1 = p.q1;
   double* ceps = p.out1 ? p.out1 + (int64_t)blockIdx.y * p.out1_bs + (int64_t)blockIdx.x * p.ld_out1 : nullptr;
@@ -310,36 +348,48 @@ __global__ __launch_bounds__(NT) void cheaptrick_kernel(const SrnWorldParams p) 
   if (!p.out0) return;
   // spectral envelope = exp(c2r(lifted cepstrum)): the transform of the symmetric sequence is real
   __syncthreads();
-  for (int j = threadIdx.x; j < N; j += NT) {
-    const int r = brev<LOG2N>(j);
-    re[r] = pw[j <= HALF ? j : N - j];
-    im[r] = 0.0;
-  }
-  fft_lds<LOG2N, NT>(re, im, tw);
+  for (int j = threadIdx.x; j < N; j += NT) ((j & 1) ? im : re)[rfft_slot<LOG2N>(j)] = pw[j <= HALF ? j : N - j];
+  rfft_lds<LOG2N, NT>(re, im, tw);
   double* sp = p.out0 + (int64_t)blockIdx.y * p.out0_bs + (int64_t)blockIdx.x * p.ld_out0;
   for (int k = threadIdx.x; k <= HALF; k += NT) sp[k] = exp(re[k]);
 }
 
 // ------------------------------------------------------------------------------------------------ D4C
-// ascending bitonic sort of a[0..n), n a power of two
+// Ascending bitonic sort of the 2 NT doubles a[0 .. 2 NT) in LDS, left in REGISTERS: thread t ends up with the sorted
+// elements 2t and 2t + 1.  Compare-exchange distance 1 stays inside the thread, distances 2 .. 64 are lane exchanges
+// inside a wave (no barrier), only distances >= 128 (6 of the 55 steps at 1024 elements) go through LDS.
 template <int NT>
-__device__ void bitonic_sort(double* a, int n) {
+__device__ __forceinline__ void bitonic_sort_pairs(double* a, double& v0, double& v1) {
+  constexpr int n = 2 * NT;
+  const int i0 = 2 * threadIdx.x;
+  v0 = a[i0];
+  v1 = a[i0 + 1];
   for (int k = 2; k <= n; k <<= 1) {
+    const bool asc = (i0 & k) == 0;  // the same for both elements (k >= 2)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      __syncthreads();
-      for (int p = threadIdx.x; p < n / 2; p += NT) {
-        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-        const int l = i | j;
-        const bool asc = (i & k) == 0;
-        const double u = a[i], v = a[l];
-        if ((u > v) == asc) {
-          a[i] = v;
-          a[l] = u;
-        }
+      if (j == 1) {
+        const double lo = fmin(v0, v1), hi = fmax(v0, v1);
+        v0 = asc ? lo : hi;
+        v1 = asc ? hi : lo;
+        continue;
       }
+      double p0, p1;
+      if (j <= 64) {
+        p0 = __shfl_xor(v0, j >> 1, 64);
+        p1 = __shfl_xor(v1, j >> 1, 64);
+      } else {
+        __syncthreads();
+        a[i0] = v0;
+        a[i0 + 1] = v1;
+        __syncthreads();
+        p0 = a[i0 ^ j];
+        p1 = a[(i0 + 1) ^ j];
+      }
+      const bool take_min = ((i0 & j) == 0) == asc;
+      v0 = take_min ? fmin(v0, p0) : fmax(v0, p0);
+      v1 = take_min ? fmin(v1, p1) : fmax(v1, p1);
     }
   }
-  __syncthreads();
 }
 
 template <int LOG2N, int NT>
@@ -372,7 +422,7 @@ __global__ __launch_bounds__(NT, 2) void d4c_kernel(const SrnWorldParams p) {
   {
     const double cur = fmax(f0, 40.0);
     windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, cur, fr.t, WIN_BLACKMAN, 3.0, false, false, re, im, scr, red);
-    fft_lds<LOG2N, NT>(re, im, tw);
+    rfft_lds<LOG2N, NT>(re, im, tw);
     const int b0 = (int)ceil(100.0 * N / fs), b1 = (int)ceil(4000.0 * N / fs), b2 = (int)ceil(7900.0 * N / fs);
     double s1 = 0.0, s2 = 0.0;
     for (int k = b0 + 1 + threadIdx.x; k <= min(b2, HALF); k += NT) {
@@ -414,7 +464,7 @@ __global__ __launch_bounds__(NT, 2) void d4c_kernel(const SrnWorldParams p) {
 
   // ---- smoothed power spectrum: Hanning window of 4 periods, DC correction, smoothing over one F0
   windowed_frame<LOG2N, NT>(fr.x, fr.x_len, fs, f0, fr.t, WIN_HANNING, 4.0, false, false, re, im, scr, red);
-  fft_lds<LOG2N, NT>(re, im, tw);
+  rfft_lds<LOG2N, NT>(re, im, tw);
   for (int k = threadIdx.x; k <= HALF; k += NT) pw[k] = re[k] * re[k] + im[k] * im[k];
   dc_correction<NT>(pw, HALF, f0, fs, N, scr);
   linear_smoothing<NT>(pw, pw, HALF, f0, fs, N, 0.0, scr, red);
@@ -435,11 +485,9 @@ __global__ __launch_bounds__(NT, 2) void d4c_kernel(const SrnWorldParams p) {
     const int center = (int)(3000.0 * (band + 1) * N / fs);
     for (int j = threadIdx.x; j < N; j += NT) {
       const int src = center - hw + j;
-      const int r = brev<LOG2N>(j);
-      re[r] = (j < wl && src >= 0 && src <= HALF) ? gd[src] * p.band_window[j] : 0.0;
-      im[r] = 0.0;
+      ((j & 1) ? im : re)[rfft_slot<LOG2N>(j)] = (j < wl && src >= 0 && src <= HALF) ? gd[src] * p.band_window[j] : 0.0;
     }
-    fft_lds<LOG2N, NT>(re, im, tw);
+    rfft_lds<LOG2N, NT>(re, im, tw);
     // powers into scr[0..HALF]; the largest one is taken out so that HALF (a power of two) values get sorted
     double best = -1.0;
     int arg = 0;
@@ -477,11 +525,15 @@ __global__ __launch_bounds__(NT, 2) void d4c_kernel(const SrnWorldParams p) {
     const double vmax = scr[amax];
     __syncthreads();
     if (threadIdx.x == 0) scr[amax] = scr[HALF];  // drop the maximum: HALF values remain in scr[0..HALF)
-    bitonic_sort<NT>(scr, HALF);
+    static_assert(HALF == 2 * NT, "bitonic_sort_pairs holds two elements per thread");
+    double e0, e1;
+    __syncthreads();
+    bitonic_sort_pairs<NT>(scr, e0, e1);
     double small = 0.0, rest = 0.0;
-    for (int k = threadIdx.x; k < HALF; k += NT) {
-      if (k < n_small) small += scr[k];
-      else rest += scr[k];
+    {
+      const int i0 = 2 * threadIdx.x;
+      if (i0 < n_small) small += e0; else rest += e0;
+      if (i0 + 1 < n_small) small += e1; else rest += e1;
     }
     small = block_sum<NT>(small, red);
     rest = block_sum<NT>(rest, red);
@@ -793,13 +845,15 @@ extern "C" int srn_world_d4c(const SrnWorldParams* p, void* stream) {
   SRN_CHECK_ARG(last_center + hw <= N / 2, "srn_world_d4c: band %d leaves the spectrum", p->n_bands);
   const int boundary = (int)(N * 8.0 / p->band_window_len + 0.5);
   SRN_CHECK_ARG(boundary >= 0 && boundary < N / 2, "srn_world_d4c: boundary %d", boundary);
+  static_assert(NT_D4C == 2048 / 4, "d4c_kernel<11> sorts two band powers per thread");
   dim3 grid(p->max_frames, p->n_batch);
   hipStream_t st = (hipStream_t)stream;
   static SrnSmemAttr a10, a11;
-  const int lds = world_lds_bytes(N, 2, NT_D4C);
+  const int nt = N / 4;  // two sorted elements per thread (bitonic_sort_pairs)
+  const int lds = world_lds_bytes(N, 2, nt);
   if (N == 1024) {
-    if (int rc = a10.ensure((const void*)(d4c_kernel<10, NT_D4C>), lds)) return rc;
-    hipLaunchKernelGGL((d4c_kernel<10, NT_D4C>), grid, dim3(NT_D4C), lds, st, *p);
+    if (int rc = a10.ensure((const void*)(d4c_kernel<10, 256>), lds)) return rc;
+    hipLaunchKernelGGL((d4c_kernel<10, 256>), grid, dim3(256), lds, st, *p);
   } else {
     if (int rc = a11.ensure((const void*)(d4c_kernel<11, NT_D4C>), lds)) return rc;
     hipLaunchKernelGGL((d4c_kernel<11, NT_D4C>), grid, dim3(NT_D4C), lds, st, *p);
