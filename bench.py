@@ -39,7 +39,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak (one MFMA pass; split-bf16 needs three)
 DTYPE = {"fp32": "f32", "bf16x3": "f32 operands as split-bf16 (hi+lo, 3 MFMA/product), f32 accumulate",
          "bf16x6": "f32 emulated on bf16 MFMA: exact hi+mid+lo operand split (24 significand bits), 6 MFMA/product, "
-                   "f32 accumulate (dropped terms <= 2^-26 per product)"}
+                   "f32 accumulate (dropped terms <= 2^-26 per product); the fused HiFi-GAN residual units (C = 32 / 64) "
+                   "and the generic / halo / strip conv kernels have no x6 variant and run exact f32 MFMA in this mode"}
 MODE_KEY = {"fp32": "exact_fp32_mode", "bf16x3": "split_bf16_mode", "bf16x6": "fp32_emulated_bf16x6_mode"}
 
 
