@@ -103,6 +103,8 @@ class PostJob:
 
     def process(self, wav_file):
         x, sr = read_wav(wav_file)
+        if np.ndim(x) != 1:
+            raise ValueError(f"{wav_file}: {np.shape(x)[1]} channels; the analysis expects mono audio")
         if sr != self.cfg["sample_rate"]:
             raise NotImplementedError(f"{wav_file}: {sr} Hz, expected {self.cfg['sample_rate']} (no resampler built)")
         f0 = self.f0_of(wav_file)

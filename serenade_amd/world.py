@@ -166,10 +166,15 @@ def _world_params(x, x_len, f0, t, n_frames, fs, fft_size):
 
 
 def _check_f0(f0, fs):
-    # WORLD itself has no bound; windows of 3-4 periods and the DC-correction span need F0 well inside the spectrum
-    top = float(f0.max()) if f0.numel() else 0.0
+    # WORLD itself has no bound; windows of 3-4 periods and the DC-correction span need F0 well inside the spectrum.
+    # Negative values would come out of `dilated_factor` as negative dilations (the reference asserts there).
+    if not f0.numel():
+        raise ValueError("empty F0 contour")
+    lo, top = (float(v) for v in torch.stack([f0.min(), f0.max()]).tolist())
     if not top < fs / 4.0:
         raise ValueError(f"F0 contour reaches {top} Hz; analysis needs F0 < fs / 4 = {fs / 4.0} Hz")
+    if not lo >= 0.0:
+        raise ValueError(f"F0 contour holds negative or non-finite values (min {lo})")
 
 
 def _cheaptrick_raw(x, x_len, f0, t, n_frames, fs, q1, f0_floor, fft_size, want_sp, want_ceps):
@@ -321,6 +326,10 @@ class Analyzer:
         wave = wave.to(torch.float32).reshape(len(f0_list), -1).contiguous()
         B = wave.size(0)
         lengths = [int(v) for v in lengths]
+        if len(lengths) != B or min(lengths) < 1 or max(lengths) > wave.size(1):
+            raise ValueError(f"lengths {lengths} do not describe a (B = {B}, N = {wave.size(1)}) batch of waveforms")
+        if any(np.asarray(f).size < 1 for f in f0_list):
+            raise ValueError("every item needs an F0 contour of at least one frame")
         n_frames = [harvest_frame_count(n, self.fs, self.frame_period) for n in lengths]
         F = max(n_frames)
         x = torch.empty(wave.shape, dtype=_F64, device=dev)
