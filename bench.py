@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the north-star size sweep (profiling runs)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the fp32 + bf16x3-attention secondary key (profiling runs)")
     ap.add_argument("--no-train", action="store_true", help="skip the estimator training-step line (SURVEY 8 f4)")
     ap.add_argument("--modes", default="fp32,bf16x6,bf16x3", help="contraction modes to time; the first is the "
                                                                   "headline (profiling runs pass one)")
@@ -502,7 +503,7 @@ def main():
             out.setdefault("multi_gpu", {})[k] = head[k]
     for m in modes[1:]:
         out[MODE_KEY[m]] = results[m]
-    if "fp32" in modes and world == 1:
+    if "fp32" in modes and world == 1 and not args.no_mixed:
         out["fp32_with_bf16x3_attention_mode"] = mixed_attention()
     if rank == 0 and world == 1 and not args.no_train:
         # a secondary line: it must never cost the headline its JSON
