@@ -9,8 +9,8 @@
 // Design: WORLD is float64 and ratio-of-small-differences arithmetic (group delay minus its smoothed self, sorted
 // band powers 60 dB apart), so everything runs in fp64 -- the MI355X issues fp64 FMAs at the fp32 rate.  ONE
 // workgroup analyses ONE frame and never leaves the CU: the F0-adaptive window is applied while gathering the
-// frame's samples from the (L2-resident) waveform, the radix-2 FFT runs in LDS (SoA planes, twiddles in LDS; real
-// data through a half-length complex transform), power
+// frame's samples from the (L2-resident) waveform, the FFT runs in LDS (SoA planes, twiddles in LDS, two radix-2
+// stages per pass; real data through a half-length complex transform), power
 // spectrum / DC correction / rectangular smoothing (a block prefix sum) / cepstral lifter / bitonic sort of the band
 // powers all work on LDS arrays, and only 513 (cepstrum) or 3 (band aperiodicity) doubles per frame go back to HBM.
 #include "common.h"
@@ -54,30 +54,58 @@ __device__ __forceinline__ void twiddle(const double* tw, int m, double& wr, dou
   wi = upper ? -t0 : t1;
 }
 
-// In-place radix-2 decimation-in-time FFT of M = 2^LOG2M complex points held as two LDS planes.  Input in
-// bit-reversed order, output in natural order.  tw is the quarter-wave table of N = M << TWSHIFT points (an M-point
-// transform walks it in steps of 2^TWSHIFT).
+// In-place decimation-in-time FFT of M = 2^LOG2M complex points held as two LDS planes.  Input in bit-reversed order,
+// output in natural order.  tw is the quarter-wave table of N = M << TWSHIFT points (an M-point transform walks it in
+// steps of 2^TWSHIFT).  Two radix-2 stages are done per pass over LDS (a thread takes the four points base + {0, h, 2h,
+// 3h}, runs both butterfly levels in registers and writes them back), a single stage first when LOG2M is odd: the
+// passes -- each a barrier plus a round trip through LDS -- are what the frame kernels are made of, so halving them
+// matters more than the flops.
 template <int LOG2M, int NT, int TWSHIFT = 0>
 __device__ void fft_lds(double* re, double* im, const double* tw) {
   constexpr int M = 1 << LOG2M;
-#pragma unroll 1
-  for (int s = 1; s <= LOG2M; ++s) {
-    const int half = 1 << (s - 1);
-    const int tstep = M >> s;
+  constexpr int LOG2N = LOG2M + TWSHIFT;
+  int s = 1;
+  if (LOG2M & 1) {  // stage 1 alone: butterflies of distance 1 with w = 1
     __syncthreads();
     for (int b = threadIdx.x; b < M / 2; b += NT) {
-      const int k = b & (half - 1);
-      const int i = ((b >> (s - 1)) << s) + k;
-      const int j = i + half;
-      double wr, wi;
-      twiddle<LOG2M + TWSHIFT>(tw, (k * tstep) << TWSHIFT, wr, wi);
-      const double xr = re[j], xi = im[j];
-      const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
-      const double ur = re[i], ui = im[i];
-      re[i] = ur + tr;
-      im[i] = ui + ti;
-      re[j] = ur - tr;
-      im[j] = ui - ti;
+      const int i = 2 * b;
+      const double ur = re[i], ui = im[i], xr = re[i + 1], xi = im[i + 1];
+      re[i] = ur + xr;
+      im[i] = ui + xi;
+      re[i + 1] = ur - xr;
+      im[i + 1] = ui - xi;
+    }
+    s = 2;
+  }
+#pragma unroll 1
+  for (; s < LOG2M; s += 2) {  // stages s and s + 1
+    const int h = 1 << (s - 1);
+    __syncthreads();
+    for (int q = threadIdx.x; q < M / 4; q += NT) {
+      const int k = q & (h - 1);
+      const int base = ((q >> (s - 1)) << (s + 1)) + k;
+      double w1r, w1i, w2r, w2i, w3r, w3i;
+      twiddle<LOG2N>(tw, (k * (M >> s)) << TWSHIFT, w1r, w1i);              // W_{2h}^k
+      twiddle<LOG2N>(tw, (k * (M >> (s + 1))) << TWSHIFT, w2r, w2i);        // W_{4h}^k
+      twiddle<LOG2N>(tw, ((k + h) * (M >> (s + 1))) << TWSHIFT, w3r, w3i);  // W_{4h}^{k+h}
+      const double x0r = re[base], x0i = im[base], x1r = re[base + h], x1i = im[base + h];
+      const double x2r = re[base + 2 * h], x2i = im[base + 2 * h], x3r = re[base + 3 * h], x3i = im[base + 3 * h];
+      // stage s: (x0, x1) and (x2, x3) with W_{2h}^k
+      const double t1r = w1r * x1r - w1i * x1i, t1i = w1r * x1i + w1i * x1r;
+      const double t3r = w1r * x3r - w1i * x3i, t3i = w1r * x3i + w1i * x3r;
+      const double a0r = x0r + t1r, a0i = x0i + t1i, a1r = x0r - t1r, a1i = x0i - t1i;
+      const double a2r = x2r + t3r, a2i = x2i + t3i, a3r = x2r - t3r, a3i = x2i - t3i;
+      // stage s + 1: (a0, a2) with W_{4h}^k, (a1, a3) with W_{4h}^{k+h}
+      const double u2r = w2r * a2r - w2i * a2i, u2i = w2r * a2i + w2i * a2r;
+      const double u3r = w3r * a3r - w3i * a3i, u3i = w3r * a3i + w3i * a3r;
+      re[base] = a0r + u2r;
+      im[base] = a0i + u2i;
+      re[base + 2 * h] = a0r - u2r;
+      im[base + 2 * h] = a0i - u2i;
+      re[base + h] = a1r + u3r;
+      im[base + h] = a1i + u3i;
+      re[base + 3 * h] = a1r - u3r;
+      im[base + 3 * h] = a1i - u3i;
     }
   }
   __syncthreads();

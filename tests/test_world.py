@@ -292,7 +292,9 @@ def test_gpu_all_unvoiced_item_is_flagged():
     an = world.Analyzer()
     in_signal, c, dfs, feats = an(_cuda(x[None], torch.float32), [4800], [np.zeros(21)])
     assert int(feats["ok"][0]) == 0 and torch.isfinite(c).all()
-    for bad in ([np.full(21, 7000.0)], [np.full(21, -5.0)], [np.array([])]):
+    # (a negative contour of another length is clamped at 0 by the length match, as in the reference; at the analysis
+    #  length -- 41 frames here -- it reaches the check)
+    for bad in ([np.full(21, 7000.0)], [np.full(41, -5.0)], [np.array([])]):
         with pytest.raises(ValueError):
             an(_cuda(x[None], torch.float32), [4800], bad)
     for bad_len in ([0], [4801], [4800, 4800]):
