@@ -4,10 +4,11 @@ SiFiGAN generator behind it, for B utterances of T mel frames (T * 240 samples e
 
 Per stage: HIP-event time, analysis frames/s, x real time, and for the two LDS-resident kernels the arithmetic they
 do per frame against the chip's peaks -- they are bound by LDS traffic and barrier latency, not by HBM:
-  CheapTrick: 3 real 1024-point transforms, each a 512-point complex radix-2 FFT (256 * 9 butterflies * 10 flop) + a
-              separation pass = 0.08 MFLOP and 3 * 10 passes * 512 points * 16 B * (read + write) = 0.49 MB of LDS traffic;
+  CheapTrick: 3 real 1024-point transforms, each a 512-point complex FFT (256 * 9 butterflies * 10 flop, two radix-2
+              stages per LDS pass) + a separation pass = 0.08 MFLOP and 3 * 6 passes * 512 points * 32 B = 0.29 MB of LDS
+              traffic;
   D4C:        5 real + 2 complex 2048-point transforms = 5 * 512 * 10 * 10 + 2 * 1024 * 11 * 10 = 0.48 MFLOP and
-              (5 * 11 * 1024 + 2 * 11 * 2048) * 32 B = 3.2 MB of LDS traffic, plus 3 bitonic sorts of 1024 doubles (mostly
+              (5 * 6 * 1024 + 2 * 6 * 2048) * 32 B = 1.7 MB of LDS traffic, plus 3 bitonic sorts of 1024 doubles (mostly
               in registers) per voiced frame.
 HBM traffic per frame is 120 new samples in (8 B each, the rest of the window hits L2) and 513 + 3 doubles out.
 Prints one JSON object.  (Values are checked against oracle/world_oracle.py in tests/test_world.py.)"""
@@ -81,13 +82,13 @@ def main():
     x_len, nf = world._i32([n] * B, dev), feats["nf"]
     ms, (_, ceps) = timed(lambda: world._cheaptrick_raw(x, x_len, f0, t, nf, FS, -0.15, 71.0, 1024, False, True))
     out["cheaptrick"] = {"ms": ms, "us_per_frame_per_cu": ms * 1e3 / frames * 256, "fp64_tflops": 0.08e6 * frames / ms / 1e9,
-                         "lds_tb_s": 0.49e6 * frames / ms / 1e9, "frames_per_s": frames / ms * 1e3}
+                         "lds_tb_s": 0.29e6 * frames / ms / 1e9, "frames_per_s": frames / ms * 1e3}
     m = world._sp2mc_matrix(dev, 513, 39, 0.466, True)
     ms, _ = timed(lambda: world._project(ceps, m, False))
     out["sp2mc_projection"] = {"ms": ms, "fp64_tflops": 2 * 513 * 40 * frames / ms / 1e9}
     ms, _ = timed(lambda: world._d4c_raw(x, x_len, f0, t, nf, FS, 0.85))
     out["d4c"] = {"ms": ms, "us_per_voiced_frame_per_cu": ms * 1e3 / max(voiced, 1) * 256,
-                  "fp64_tflops": 0.48e6 * voiced / ms / 1e9, "lds_tb_s": 3.2e6 * voiced / ms / 1e9,
+                  "fp64_tflops": 0.48e6 * voiced / ms / 1e9, "lds_tb_s": 1.7e6 * voiced / ms / 1e9,
                   "frames_per_s": frames / ms * 1e3}
     ms, _ = timed(lambda: an.excitation(feats))
     out["excitation_with_noise_draw"] = {"ms": ms}
