@@ -576,6 +576,10 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int 
       case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 0>>(p, false, stream);
       case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 0>>(p, false, stream);
       case 5: return launch_fast<FCfg<128, 32, 32, 32, 2, 0>>(p, false, stream);
+      case 6: return launch_fast<FCfg<128, 128, 64, 64, 1, 0>>(p, false, stream);  // single LDS stage
+      case 7: return launch_fast<FCfg<64, 64, 32, 32, 1, 0>>(p, false, stream);
+      case 8: return launch_fast<FCfg<128, 64, 32, 64, 1, 0>>(p, false, stream);
+      case 9: return launch_fast<FCfg<64, 128, 32, 64, 1, 0>>(p, false, stream);
       default: return 0;
     }
   }

@@ -446,6 +446,17 @@ int launch(const SrnConvParams& p, hipStream_t stream) {
 }
 
 int pick_tile(const SrnConvParams& p) {
+  // Exact fp32: the single-LDS-stage forms (ids 6-9, conv_fast.hip) win on every shape of the path (opbench --fp32
+  // --sweep, r3): an fp32 MFMA is 64 cycles, so the loop is MFMA-bound with one stage, and the halved LDS footprint lets
+  // 4-6 workgroups share a CU -- their staggered fills / epilogues cover each other, which two double-buffered
+  // workgroups running in lockstep do not.  64 x 64 (id 7) for N = 512 .. 6144 (+4 .. +9 % over its two-stage form),
+  // 64 x 128 (id 9) for the GEGLU projection and the N = 128 / 256 HiFi-GAN stages (+3 .. +6 %).
+  if (p.precision == SRN_PREC_FP32 && !p.w_nmajor && p.C_in % 32 == 0) {
+    if (p.geglu) return 9;
+    const int64_t z = (int64_t)p.n_batch * p.n_head;
+    if (p.N % 128 == 0 && p.N <= 256 && z * ((p.T_out + 63) / 64) * (p.N / 128) >= 512) return 9;
+    if (p.N % 64 == 0) return 7;
+  }
   float best = -1.f;
   int best_id = 4;
   const double z = (double)p.n_batch * p.n_head;
@@ -518,7 +529,7 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
   }
 
   int tile = p.tile > 0 ? p.tile : pick_tile(p);
-  if (p.geglu && !(tile == 1 || tile == 2 || tile == 3)) tile = 1;
+  if (p.geglu && !(tile == 1 || tile == 2 || tile == 3 || tile == 6 || tile == 8 || tile == 9)) tile = 1;
   if (p.ws != nullptr && p.tile <= 0 && p.no_halo != 3) {
     // small grids with a deep contraction (B = 1 / short utterances): slice K over extra workgroups, reduce after
     const int ks = srn_splitk_plan(p);
@@ -542,6 +553,8 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
     const int r = srn_conv_fast_try(p, tile, stream);
     if (r != 0) return r < 0 ? r : 0;
   }
+  // single-stage ids exist only in conv_fast.hip: their two-stage twins here
+  tile = tile == 6 ? 1 : tile == 7 ? 4 : tile == 8 ? 2 : tile == 9 ? 3 : tile;
   if (p.w_nmajor) {
     switch (tile) {
       case 1: return launch<Cfg<128, 128, 64, 64, true>>(p, stream);
