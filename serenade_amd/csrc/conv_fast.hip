@@ -591,6 +591,9 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int 
       case 3: return launch_fast<FCfg<64, 128, 32, 64, 2, 2>>(p, wpl, stream);
       case 4: return launch_fast<FCfg<64, 64, 32, 32, 2, 2>>(p, wpl, stream);
       case 5: return launch_fast<FCfg<128, 32, 32, 32, 2, 2>>(p, wpl, stream);
+      case 7: return launch_fast<FCfg<64, 64, 32, 32, 1, 2>>(p, wpl, stream);
+      case 8: return launch_fast<FCfg<128, 64, 32, 64, 1, 2>>(p, wpl, stream);
+      case 9: return launch_fast<FCfg<64, 128, 32, 64, 1, 2>>(p, wpl, stream);
       default: return 0;
     }
   }
@@ -601,6 +604,9 @@ int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int 
     case 4: return launch_fast<FCfg<64, 64, 32, 32>>(p, wpl, stream);
     case 5: return launch_fast<FCfg<128, 32, 32, 32>>(p, wpl, stream);
     case 6: return launch_fast<FCfg<128, 128, 64, 64, 1>>(p, wpl, stream);  // single LDS stage, 3 workgroups / CU
+    case 7: return launch_fast<FCfg<64, 64, 32, 32, 1>>(p, wpl, stream);
+    case 8: return launch_fast<FCfg<128, 64, 32, 64, 1>>(p, wpl, stream);
+    case 9: return launch_fast<FCfg<64, 128, 32, 64, 1>>(p, wpl, stream);
     default: return 0;
   }
 }

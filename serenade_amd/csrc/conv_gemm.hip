@@ -451,11 +451,14 @@ int pick_tile(const SrnConvParams& p) {
   // 4-6 workgroups share a CU -- their staggered fills / epilogues cover each other, which two double-buffered
   // workgroups running in lockstep do not.  64 x 64 (id 7) for N = 512 .. 6144 (+4 .. +9 % over its two-stage form),
   // 64 x 128 (id 9) for the GEGLU projection and the N = 128 / 256 HiFi-GAN stages (+3 .. +6 %).
+  // They need company: with fewer than ~3 workgroups per CU (B = 1, short utterances) nothing covers a single-stage
+  // workgroup's fill and the double-buffered forms below are ahead (B = 1 x T = 256: 16.7 vs 18.3 ms).
   if (p.precision == SRN_PREC_FP32 && !p.w_nmajor && p.C_in % 32 == 0) {
-    if (p.geglu) return 9;
-    const int64_t z = (int64_t)p.n_batch * p.n_head;
-    if (p.N % 128 == 0 && p.N <= 256 && z * ((p.T_out + 63) / 64) * (p.N / 128) >= 512) return 9;
-    if (p.N % 64 == 0) return 7;
+    const int64_t rows = (int64_t)p.n_batch * p.n_head * ((p.T_out + 63) / 64);
+    const int64_t blocks9 = rows * ((p.N + 127) / 128), blocks7 = rows * ((p.N + 63) / 64);
+    if (p.geglu && blocks9 >= 512) return 9;
+    if (p.N % 128 == 0 && p.N <= 256 && blocks9 >= 512) return 9;
+    if (!p.geglu && p.N % 64 == 0 && blocks7 >= 512) return 7;
   }
   float best = -1.f;
   int best_id = 4;
@@ -479,6 +482,12 @@ int pick_tile(const SrnConvParams& p) {
       best_id = t.id;
     }
   }
+  // bf16x6: wherever the model settles on the 64 x 64 tile, its single-stage form (id 7) is ahead on every shape of the
+  // path (+1 .. +14 %, opbench --bf16x6 --sweep): same reason as in exact fp32, six MFMAs per product keep the loop
+  // MFMA-bound.  (Split-bf16 x3 is LDS- / power-bound instead and the single-stage forms lose as often as they win.)
+  if (best_id == 4 && p.precision == SRN_PREC_BF16X6 && !p.w_nmajor && p.C_in % 32 == 0 &&
+      (int64_t)p.n_batch * p.n_head * ((p.T_out + 63) / 64) * ((p.N + 63) / 64) >= 512)
+    best_id = 7;
   return best_id;
 }
 
