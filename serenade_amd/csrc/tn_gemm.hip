@@ -15,6 +15,7 @@
 // SLICE ORDER (bit-reproducible, no atomics) and scales.  Attention gradients (one problem per batch x head, K = L)
 // fill the chip without slicing and store directly.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "conv_common.h"
@@ -22,13 +23,20 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int PITCH = BM + 4;  // floats per k-row of a slab (16-B aligned rows, banks rotate by 4 per row)
-constexpr int SLAB = BK * PITCH;
+constexpr int BK = 16;
 constexpr int MAX_SPLIT = 32;
 
+// TB = tile edge (128 or 64): 4 waves, each a (TB/2) x (TB/2) block of 32 x 32 MFMA tiles.
+template <int TB>
 __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p, const int m_tiles, const int n_tiles,
                                                           const int ksplit, const int k_per) {
+  constexpr int BM = TB, BN = TB;
+  constexpr int PITCH = TB + 4;       // floats per k-row of a slab (16-B aligned rows, banks rotate by 4 per row)
+  constexpr int SLAB = BK * PITCH;
+  constexpr int WT = TB / 64;         // 32 x 32 tiles per wave per direction
+  constexpr int F4 = TB / 4;          // float4 pieces per slab row
+  constexpr int ROWS_PER_PASS = 256 / F4;
+  constexpr int NLD = BK / ROWS_PER_PASS;  // float4 loads per thread per operand per step (2 at 128, 1 at 64)
   __shared__ __attribute__((aligned(16))) float lds[2][2][SLAB];  // [stage][A | B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,14 +53,14 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
   const int k_begin = slice * k_per, k_end = min(K, k_begin + k_per);
   const int n_inner = p.n_inner > 1 ? p.n_inner : 1;
 
-  // global -> register -> LDS: per step each operand is 16 rows x 128 floats = 512 float4: two per thread
-  const int lrow = tid >> 5;        // 0..7 (+8)
-  const int lcol = (tid & 31) * 4;  // float offset in the 128-wide slab row
-  float4 ra[2], rb[2];
+  // global -> register -> LDS: per step each operand is 16 rows x TB floats
+  const int lrow = tid / F4;
+  const int lcol = (tid % F4) * 4;  // float offset in the slab row
+  float4 ra[NLD], rb[NLD];
   auto load = [&](const int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = k0 + lrow + 8 * i;
+    for (int i = 0; i < NLD; ++i) {
+      const int r = k0 + lrow + ROWS_PER_PASS * i;
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
       if (r < k_end) {
         const int item = r / p.T_a, t = r - item * p.T_a;
@@ -71,20 +79,19 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
   };
   auto store = [&](const int st) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&lds[st][0][(lrow + 8 * i) * PITCH + lcol]) = ra[i];
-      *reinterpret_cast<float4*>(&lds[st][1][(lrow + 8 * i) * PITCH + lcol]) = rb[i];
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<float4*>(&lds[st][0][(lrow + ROWS_PER_PASS * i) * PITCH + lcol]) = ra[i];
+      *reinterpret_cast<float4*>(&lds[st][1][(lrow + ROWS_PER_PASS * i) * PITCH + lcol]) = rb[i];
     }
   };
 
-  // wave tile 64 x 64: waves 2 (m) x 2 (n)
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * (TB / 2), wn0 = (wave & 1) * (TB / 2);
   const int fm = lane & 31, fk = lane >> 5;
-  f32x16 acc[2][2];
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -102,12 +109,16 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int row = (kk + fk) * PITCH;
-      const float a0 = la[row + wm0 + fm], a1 = la[row + wm0 + 32 + fm];
-      const float b0 = lb[row + wn0 + fm], b1 = lb[row + wn0 + 32 + fm];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[WT], bv[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        av[i] = la[row + wm0 + 32 * i + fm];
+        bv[i] = lb[row + wn0 + 32 * i + fm];
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (s + 1 < n_steps) store(cur ^ 1);
     __syncthreads();
@@ -126,9 +137,9 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
     alpha = p.alpha;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WT; ++j) {
       const int col = n0 + wn0 + 32 * j + (lane & 31);
       if (col >= p.N) continue;
 #pragma unroll
@@ -159,9 +170,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p,
   *reinterpret_cast<float4*>(o) = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
 }
 
-int plan_split(const SrnTnGemmParams& p, int& k_per) {
+int plan_split(const SrnTnGemmParams& p, int TB, int& k_per) {
   const int64_t K = (int64_t)p.n_items * p.T_a;
-  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.n_shifts * p.n_batch * p.n_head;
+  const int64_t tiles = (int64_t)((p.M + TB - 1) / TB) * ((p.N + TB - 1) / TB) * p.n_shifts * p.n_batch * p.n_head;
   int ks = 1;
   // ~3 workgroups per CU wanted, never fewer than 8 slabs per slice.  Swept on the training step's shapes
   // (tools/tnbench.py, B = 4 x L = 1024): targets 256 / 384 / 512 / 768 / 1024 give 57 / 67 / 75 / 79 / 77 TFLOP/s overall
@@ -178,12 +189,26 @@ int plan_split(const SrnTnGemmParams& p, int& k_per) {
   return ks < 1 ? 1 : ks;
 }
 
+// tile edge.  Measured on the training step's shapes (tools/tnbench.py, B = 4 x L = 1024; SRN_TN_TILE forces one):
+// 64 wins only where 128-tiles leave the chip nearly empty even after slicing -- the two narrow weight gradients
+// (512 x 256: 27 vs 32 us, 80 x 512: 22 vs 31 us) and short contractions that cannot be sliced further
+// (attention dV at L = 512: 62 vs 71 us); everywhere else 128 is 8-40 % faster (twice the MFMA work per LDS byte)
+int tile_edge(const SrnTnGemmParams& p) {
+  static const int forced = getenv("SRN_TN_TILE") ? atoi(getenv("SRN_TN_TILE")) : 0;
+  if (forced == 64 || forced == 128) return forced;
+  const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.n_shifts * p.n_batch * p.n_head;
+  const int64_t K = (int64_t)p.n_items * p.T_a;
+  if (tiles128 <= 8) return 64;
+  if (K <= 512 && tiles128 < 384) return 64;
+  return 128;
+}
+
 }  // namespace
 
 extern "C" int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p) {
   if (p == nullptr || p->M <= 0 || p->N <= 0 || p->n_items <= 0 || p->T_a <= 0 || p->n_shifts <= 0) return 0;
   int k_per = 0;
-  const int ks = plan_split(*p, k_per);
+  const int ks = plan_split(*p, tile_edge(*p), k_per);
   if (ks <= 1) return 0;
   return (int64_t)ks * p->n_batch * p->n_head * p->M * p->n_shifts * p->N * (int64_t)sizeof(float);
 }
@@ -209,7 +234,8 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   SRN_CHECK_ARG(p.ldc >= p.n_shifts * p.N, "tn_gemm: ldc %d < n_shifts * N", p.ldc);
   SRN_CHECK_ARG((int64_t)p.n_items * p.T_a < (1ll << 31), "tn_gemm: contraction too long");
   int k_per = 0;
-  int ks = plan_split(p, k_per);
+  const int TB = tile_edge(p);
+  int ks = plan_split(p, TB, k_per);
   if (ks > 1) {
     const int64_t need = (int64_t)ks * p.n_batch * p.n_head * p.M * p.n_shifts * p.N * (int64_t)sizeof(float);
     if (p.ws == nullptr || p.ws_bytes < need || (reinterpret_cast<uintptr_t>(p.ws) & 15) != 0) {
@@ -217,11 +243,12 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
       k_per = (int)(((int64_t)p.n_items * p.T_a + BK - 1) / BK * BK);
     }
   }
-  const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
+  const int m_tiles = (p.M + TB - 1) / TB, n_tiles = (p.N + TB - 1) / TB;
   const int64_t gz = (int64_t)p.n_batch * p.n_head * ks;
   SRN_CHECK_ARG(gz <= 65535 && (int64_t)m_tiles * n_tiles < (1ll << 31), "tn_gemm: grid too large");
-  hipLaunchKernelGGL(tn_gemm_kernel, dim3(m_tiles * n_tiles, p.n_shifts, (unsigned)gz), dim3(256), 0, stream, p,
-                     m_tiles, n_tiles, ks, k_per);
+  const dim3 grid(m_tiles * n_tiles, p.n_shifts, (unsigned)gz);
+  if (TB == 64) hipLaunchKernelGGL(tn_gemm_kernel<64>, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
+  else hipLaunchKernelGGL(tn_gemm_kernel<128>, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
   if (ks > 1) {
     const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, ks);
