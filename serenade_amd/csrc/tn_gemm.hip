@@ -23,15 +23,16 @@
 
 namespace {
 
-constexpr int BK = 16;
 constexpr int MAX_SPLIT = 32;
 
 // TB = tile edge (128 or 64): 4 waves, each a (TB/2) x (TB/2) block of 32 x 32 MFMA tiles.
-template <int TB>
+template <int TB, int BK>
 __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p, const int m_tiles, const int n_tiles,
                                                           const int ksplit, const int k_per) {
   constexpr int BM = TB, BN = TB;
-  constexpr int PITCH = TB + 4;       // floats per k-row of a slab (16-B aligned rows, banks rotate by 4 per row)
+  // floats per k-row of a slab: 16-B aligned rows, banks rotate by 4 per row; unpadded where the padded pair of
+  // double-buffered slabs would pass the 64 KB static limit (a half-wave reads one row: still conflict-free)
+  constexpr int PITCH = (2 * 2 * BK * (TB + 4) * 4 > 65536) ? TB : TB + 4;
   constexpr int SLAB = BK * PITCH;
   constexpr int WT = TB / 64;         // 32 x 32 tiles per wave per direction
   constexpr int F4 = TB / 4;          // float4 pieces per slab row
@@ -57,24 +58,46 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
   const int lrow = tid / F4;
   const int lcol = (tid % F4) * 4;  // float offset in the slab row
   float4 ra[NLD], rb[NLD];
-  auto load = [&](const int k0) {
+  // per load slot: the contraction row r = item * T_a + t it fetches next, kept as (t, row pointers) and advanced by BK
+  // rows per step -- the divisions that split r happen once here and again only when a slot crosses into the next item
+  int lr[NLD], lt[NLD], litem[NLD];
+  const float *pa[NLD], *pb[NLD];
+  auto seat = [&](const int i) {  // pointers of slot i at (litem, lt)
+    const int i1 = litem[i] / n_inner, i2 = litem[i] - i1 * n_inner;  // items may be a 2-level grid (conv2d: batch x row)
+    pa[i] = A + (int64_t)i1 * p.a_is + (int64_t)i2 * p.a_is2 + (int64_t)lt[i] * p.lda + m0 + lcol;
+    pb[i] = Bm + (int64_t)i1 * p.b_is + (int64_t)i2 * p.b_is2 + ((int64_t)lt[i] * p.stride + shift) * p.ldb + n0 + lcol;
+  };
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    lr[i] = k_begin + lrow + ROWS_PER_PASS * i;
+    litem[i] = lr[i] / p.T_a;
+    lt[i] = lr[i] - litem[i] * p.T_a;
+    seat(i);
+  }
+  const bool a_in = m0 + lcol < p.M, b_in = n0 + lcol < p.N;
+  const int64_t a_step = (int64_t)BK * p.lda, b_step = (int64_t)BK * p.stride * p.ldb;
+  auto load = [&]() {  // fetch the slots' rows, then advance them one step
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int r = k0 + lrow + ROWS_PER_PASS * i;
       float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      if (r < k_end) {
-        const int item = r / p.T_a, t = r - item * p.T_a;
-        const int i1 = item / n_inner, i2 = item - i1 * n_inner;  // items may be a 2-level grid (conv2d: batch x row)
-        if (m0 + lcol < p.M)
-          va = *reinterpret_cast<const float4*>(A + (int64_t)i1 * p.a_is + (int64_t)i2 * p.a_is2 + (int64_t)t * p.lda +
-                                                m0 + lcol);
-        const int tb = t * p.stride + shift;
-        if (tb >= 0 && tb < p.T_b && n0 + lcol < p.N)
-          vb = *reinterpret_cast<const float4*>(Bm + (int64_t)i1 * p.b_is + (int64_t)i2 * p.b_is2 + (int64_t)tb * p.ldb +
-                                                n0 + lcol);
+      if (lr[i] < k_end) {
+        if (a_in) va = *reinterpret_cast<const float4*>(pa[i]);
+        const int tb = lt[i] * p.stride + shift;
+        if (tb >= 0 && tb < p.T_b && b_in) vb = *reinterpret_cast<const float4*>(pb[i]);
       }
       ra[i] = va;
       rb[i] = vb;
+      lr[i] += BK;
+      lt[i] += BK;
+      pa[i] += a_step;
+      pb[i] += b_step;
+      if (lt[i] >= p.T_a) {
+        do {
+          lt[i] -= p.T_a;
+          ++litem[i];
+        } while (lt[i] >= p.T_a);
+        seat(i);
+      }
     }
   };
   auto store = [&](const int st) {
@@ -97,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
 
   const int n_steps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
   if (n_steps > 0) {
-    load(k_begin);
+    load();
     store(0);
   }
   __syncthreads();
   for (int s = 0; s < n_steps; ++s) {
     const int cur = s & 1;
-    if (s + 1 < n_steps) load(k_begin + (s + 1) * BK);
+    if (s + 1 < n_steps) load();
     const float* la = &lds[cur][0][0];
     const float* lb = &lds[cur][1][0];
 #pragma unroll
@@ -170,13 +193,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p,
   *reinterpret_cast<float4*>(o) = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
 }
 
-int plan_split(const SrnTnGemmParams& p, int TB, int& k_per) {
+int plan_split(const SrnTnGemmParams& p, int TB, int BK, int& k_per) {
   const int64_t K = (int64_t)p.n_items * p.T_a;
   const int64_t tiles = (int64_t)((p.M + TB - 1) / TB) * ((p.N + TB - 1) / TB) * p.n_shifts * p.n_batch * p.n_head;
   int ks = 1;
   // ~3 workgroups per CU wanted, never fewer than 8 slabs per slice.  Swept on the training step's shapes
   // (tools/tnbench.py, B = 4 x L = 1024): targets 256 / 384 / 512 / 768 / 1024 give 57 / 67 / 75 / 79 / 77 TFLOP/s overall
-  constexpr int target = 768;
+  static const int target = getenv("SRN_TN_TARGET") ? atoi(getenv("SRN_TN_TARGET")) : 768;
   if (tiles < target / 2) {
     ks = (int)((target + tiles - 1) / tiles);
     const int64_t cap = K / (8 * BK);
@@ -193,6 +216,12 @@ int plan_split(const SrnTnGemmParams& p, int TB, int& k_per) {
 // 64 wins only where 128-tiles leave the chip nearly empty even after slicing -- the two narrow weight gradients
 // (512 x 256: 27 vs 32 us, 80 x 512: 22 vs 31 us) and short contractions that cannot be sliced further
 // (attention dV at L = 512: 62 vs 71 us); everywhere else 128 is 8-40 % faster (twice the MFMA work per LDS byte)
+int slab_rows(int TB) {
+  static const int forced = getenv("SRN_TN_BK") ? atoi(getenv("SRN_TN_BK")) : 0;
+  if (forced == 16 || forced == 32) return forced;
+  return 16;
+}
+
 int tile_edge(const SrnTnGemmParams& p) {
   static const int forced = getenv("SRN_TN_TILE") ? atoi(getenv("SRN_TN_TILE")) : 0;
   if (forced == 64 || forced == 128) return forced;
@@ -208,7 +237,8 @@ int tile_edge(const SrnTnGemmParams& p) {
 extern "C" int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p) {
   if (p == nullptr || p->M <= 0 || p->N <= 0 || p->n_items <= 0 || p->T_a <= 0 || p->n_shifts <= 0) return 0;
   int k_per = 0;
-  const int ks = plan_split(*p, tile_edge(*p), k_per);
+  const int TB = tile_edge(*p);
+  const int ks = plan_split(*p, TB, slab_rows(TB), k_per);
   if (ks <= 1) return 0;
   return (int64_t)ks * p->n_batch * p->n_head * p->M * p->n_shifts * p->N * (int64_t)sizeof(float);
 }
@@ -235,7 +265,8 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   SRN_CHECK_ARG((int64_t)p.n_items * p.T_a < (1ll << 31), "tn_gemm: contraction too long");
   int k_per = 0;
   const int TB = tile_edge(p);
-  int ks = plan_split(p, TB, k_per);
+  const int BK = slab_rows(TB);
+  int ks = plan_split(p, TB, BK, k_per);
   if (ks > 1) {
     const int64_t need = (int64_t)ks * p.n_batch * p.n_head * p.M * p.n_shifts * p.N * (int64_t)sizeof(float);
     if (p.ws == nullptr || p.ws_bytes < need || (reinterpret_cast<uintptr_t>(p.ws) & 15) != 0) {
@@ -247,8 +278,9 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   const int64_t gz = (int64_t)p.n_batch * p.n_head * ks;
   SRN_CHECK_ARG(gz <= 65535 && (int64_t)m_tiles * n_tiles < (1ll << 31), "tn_gemm: grid too large");
   const dim3 grid(m_tiles * n_tiles, p.n_shifts, (unsigned)gz);
-  if (TB == 64) hipLaunchKernelGGL(tn_gemm_kernel<64>, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
-  else hipLaunchKernelGGL(tn_gemm_kernel<128>, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
+  auto kern = TB == 64 ? (BK == 32 ? tn_gemm_kernel<64, 32> : tn_gemm_kernel<64, 16>)
+                       : (BK == 32 ? tn_gemm_kernel<128, 32> : tn_gemm_kernel<128, 16>);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
   if (ks > 1) {
     const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, ks);
