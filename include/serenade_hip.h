@@ -400,7 +400,7 @@ int srn_sifigan_excitation(const SrnExcitationParams* p, void* stream);
  *
  *   out[z, m, j * N + n] = alpha * sum_{item, t} a[z, item, t, m] * b[z, item, t * stride + shift[j], n]
  *
- * with rows of b outside [0, T_b) read as zero.  z = zb * n_head + zh walks independent problems.
+ * with rows of b outside [0, T_b) -- or [0, len_b[item]) -- read as zero.  z = zb * n_head + zh walks independent problems.
  *   weight gradient of a conv:  a = dY (B items of T_out rows, M = C_out), b = X (T_in rows, N = C_in), shift = taps
  *                               -> dW in the packed layout (C_out, taps * C_in) srn_conv_gemm reads;
  *   attention:  dV = P^T dO and dK = dS^T Q, one problem per (batch, head), n_items = 1, T_a = T_b = L.
@@ -421,6 +421,11 @@ typedef struct SrnTnGemmParams {
   float* ws; int64_t ws_bytes;  /* or NULL: no slicing */
   int32_t n_inner;              /* > 1: item i = (i / n_inner, i % n_inner) with strides (x_is, x_is2) -- conv2d's */
   int64_t a_is2, b_is2;         /* (batch, output row) items; 0 / 1: one level */
+  const int32_t* len_b;         /* or NULL; (n_batch, n_items), one-level items only: rows of b at or past len_b[zb, item]
+                                 * read as zero -- the `x * mask` in front of the reference's convs (decoder.py:66-101),
+                                 * as srn_conv_gemm's len_in does it in the forward */
+  float* colsum;                /* or NULL; (M,), one problem, M % 4 == 0: alpha * sum_{item, t} a[item, t, m] -- a
+                                 * conv's bias gradient (the column sums of dY), added in the same slice order */
 } SrnTnGemmParams;
 int srn_tn_gemm(const SrnTnGemmParams* p, void* stream);
 int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p);

@@ -76,7 +76,7 @@ class SrnTnGemmParams(ctypes.Structure):
         ("b", c_void_p), ("b_bs", c_int64), ("b_hs", c_int64), ("b_is", c_int64), ("ldb", c_int32),
         ("out", c_void_p), ("out_bs", c_int64), ("out_hs", c_int64), ("ldc", c_int32),
         ("alpha", c_float), ("ws", c_void_p), ("ws_bytes", c_int64),
-        ("n_inner", c_int32), ("a_is2", c_int64), ("b_is2", c_int64),
+        ("n_inner", c_int32), ("a_is2", c_int64), ("b_is2", c_int64), ("len_b", c_void_p), ("colsum", c_void_p),
     ]
 
 

@@ -24,9 +24,10 @@
 namespace {
 
 constexpr int MAX_SPLIT = 32;
+constexpr int BK = 16;  // rows per LDS slab (32 measured no faster: 77.5 vs 78.2 TFLOP/s overall)
 
 // TB = tile edge (128 or 64): 4 waves, each a (TB/2) x (TB/2) block of 32 x 32 MFMA tiles.
-template <int TB, int BK>
+template <int TB>
 __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p, const int m_tiles, const int n_tiles,
                                                           const int ksplit, const int k_per) {
   constexpr int BM = TB, BN = TB;
@@ -60,12 +61,13 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
   float4 ra[NLD], rb[NLD];
   // per load slot: the contraction row r = item * T_a + t it fetches next, kept as (t, row pointers) and advanced by BK
   // rows per step -- the divisions that split r happen once here and again only when a slot crosses into the next item
-  int lr[NLD], lt[NLD], litem[NLD];
+  int lr[NLD], lt[NLD], litem[NLD], lend[NLD];  // lend: rows of b at or past it read as zero (T_b, or the item's len_b)
   const float *pa[NLD], *pb[NLD];
   auto seat = [&](const int i) {  // pointers of slot i at (litem, lt)
     const int i1 = litem[i] / n_inner, i2 = litem[i] - i1 * n_inner;  // items may be a 2-level grid (conv2d: batch x row)
     pa[i] = A + (int64_t)i1 * p.a_is + (int64_t)i2 * p.a_is2 + (int64_t)lt[i] * p.lda + m0 + lcol;
     pb[i] = Bm + (int64_t)i1 * p.b_is + (int64_t)i2 * p.b_is2 + ((int64_t)lt[i] * p.stride + shift) * p.ldb + n0 + lcol;
+    lend[i] = p.len_b != nullptr && litem[i] < p.n_items ? min(p.T_b, p.len_b[zb * p.n_items + litem[i]]) : p.T_b;
   };
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
       if (lr[i] < k_end) {
         if (a_in) va = *reinterpret_cast<const float4*>(pa[i]);
         const int tb = lt[i] * p.stride + shift;
-        if (tb >= 0 && tb < p.T_b && b_in) vb = *reinterpret_cast<const float4*>(pb[i]);
+        if (tb >= 0 && tb < lend[i] && b_in) vb = *reinterpret_cast<const float4*>(pb[i]);
       }
       ra[i] = va;
       rb[i] = vb;
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // column sums of a (a conv's bias gradient) ride along in the workgroups of the first column of tiles: thread m adds
+  // the slab's BK values of column m after the slab's barrier -- 16 conflict-free LDS reads beside 32 MFMAs
+  const bool do_cs = p.colsum != nullptr && nt == 0 && tap == 0;
+  float csum = 0.f;
   const int n_steps = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
   if (n_steps > 0) {
     load();
@@ -143,8 +149,18 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+    if (do_cs && tid < TB) {
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) csum += la[kk * PITCH + tid];
+    }
     if (s + 1 < n_steps) store(cur ^ 1);
     __syncthreads();
+  }
+  if (do_cs && tid < TB && m0 + tid < p.M) {
+    if (ksplit > 1)
+      p.ws[(int64_t)ksplit * p.n_batch * p.n_head * p.M * p.n_shifts * p.N + (int64_t)slice * p.M + m0 + tid] = csum;
+    else
+      p.colsum[m0 + tid] = csum * p.alpha;
   }
 
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -179,7 +195,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p,
   const int64_t per_z = (int64_t)p.M * cols;
   const int64_t Z = (int64_t)p.n_batch * p.n_head;
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= Z * per_z) return;
+  if (i4 >= Z * per_z) {  // the blocks past the tiles: column sums (M % 4 == 0, Z == 1), slices in order too
+    const int64_t m = i4 - Z * per_z;
+    if (p.colsum == nullptr || m >= p.M) return;
+    const float* w = p.ws + (int64_t)ksplit * Z * per_z + m;
+    float4 v = *reinterpret_cast<const float4*>(w);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(w + (int64_t)s * p.M);
+      v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(p.colsum + m) = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
+    return;
+  }
   const int64_t z = i4 / per_z, rem = i4 - z * per_z;
   const int64_t m = rem / cols, c = rem - m * cols;
   const float* w = p.ws + i4;
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p,
   *reinterpret_cast<float4*>(o) = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
 }
 
-int plan_split(const SrnTnGemmParams& p, int TB, int BK, int& k_per) {
+int plan_split(const SrnTnGemmParams& p, int TB, int& k_per) {
   const int64_t K = (int64_t)p.n_items * p.T_a;
   const int64_t tiles = (int64_t)((p.M + TB - 1) / TB) * ((p.N + TB - 1) / TB) * p.n_shifts * p.n_batch * p.n_head;
   int ks = 1;
@@ -216,10 +243,9 @@ int plan_split(const SrnTnGemmParams& p, int TB, int BK, int& k_per) {
 // 64 wins only where 128-tiles leave the chip nearly empty even after slicing -- the two narrow weight gradients
 // (512 x 256: 27 vs 32 us, 80 x 512: 22 vs 31 us) and short contractions that cannot be sliced further
 // (attention dV at L = 512: 62 vs 71 us); everywhere else 128 is 8-40 % faster (twice the MFMA work per LDS byte)
-int slab_rows(int TB) {
-  static const int forced = getenv("SRN_TN_BK") ? atoi(getenv("SRN_TN_BK")) : 0;
-  if (forced == 16 || forced == 32) return forced;
-  return 16;
+// partial tiles of every slice, then (with colsum) the slices' partial column sums
+int64_t ws_floats(const SrnTnGemmParams& p, int ks) {
+  return (int64_t)ks * p.n_batch * p.n_head * p.M * p.n_shifts * p.N + (p.colsum != nullptr ? (int64_t)ks * p.M : 0);
 }
 
 int tile_edge(const SrnTnGemmParams& p) {
@@ -238,9 +264,9 @@ extern "C" int64_t srn_tn_gemm_workspace_bytes(const SrnTnGemmParams* p) {
   if (p == nullptr || p->M <= 0 || p->N <= 0 || p->n_items <= 0 || p->T_a <= 0 || p->n_shifts <= 0) return 0;
   int k_per = 0;
   const int TB = tile_edge(*p);
-  const int ks = plan_split(*p, TB, slab_rows(TB), k_per);
+  const int ks = plan_split(*p, TB, k_per);
   if (ks <= 1) return 0;
-  return (int64_t)ks * p->n_batch * p->n_head * p->M * p->n_shifts * p->N * (int64_t)sizeof(float);
+  return ws_floats(*p, ks) * (int64_t)sizeof(float);
 }
 
 extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
@@ -263,12 +289,15 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
                 "16-byte aligned");
   SRN_CHECK_ARG(p.ldc >= p.n_shifts * p.N, "tn_gemm: ldc %d < n_shifts * N", p.ldc);
   SRN_CHECK_ARG((int64_t)p.n_items * p.T_a < (1ll << 31), "tn_gemm: contraction too long");
+  SRN_CHECK_ARG(p.colsum == nullptr || (p.n_batch == 1 && p.n_head == 1 && p.M % 4 == 0 &&
+                                        (reinterpret_cast<uintptr_t>(p.colsum) & 15) == 0),
+                "tn_gemm: colsum needs one problem (n_batch = n_head = 1), M %% 4 == 0 and a 16-byte aligned pointer");
+  SRN_CHECK_ARG(p.len_b == nullptr || p.n_inner <= 1, "tn_gemm: len_b is per item of a one-level item grid");
   int k_per = 0;
   const int TB = tile_edge(p);
-  const int BK = slab_rows(TB);
-  int ks = plan_split(p, TB, BK, k_per);
+  int ks = plan_split(p, TB, k_per);
   if (ks > 1) {
-    const int64_t need = (int64_t)ks * p.n_batch * p.n_head * p.M * p.n_shifts * p.N * (int64_t)sizeof(float);
+    const int64_t need = ws_floats(p, ks) * (int64_t)sizeof(float);
     if (p.ws == nullptr || p.ws_bytes < need || (reinterpret_cast<uintptr_t>(p.ws) & 15) != 0) {
       ks = 1;  // no (or too small a) workspace: correct, just fewer workgroups
       k_per = (int)(((int64_t)p.n_items * p.T_a + BK - 1) / BK * BK);
@@ -278,11 +307,10 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   const int64_t gz = (int64_t)p.n_batch * p.n_head * ks;
   SRN_CHECK_ARG(gz <= 65535 && (int64_t)m_tiles * n_tiles < (1ll << 31), "tn_gemm: grid too large");
   const dim3 grid(m_tiles * n_tiles, p.n_shifts, (unsigned)gz);
-  auto kern = TB == 64 ? (BK == 32 ? tn_gemm_kernel<64, 32> : tn_gemm_kernel<64, 16>)
-                       : (BK == 32 ? tn_gemm_kernel<128, 32> : tn_gemm_kernel<128, 16>);
+  auto kern = TB == 64 ? tn_gemm_kernel<64> : tn_gemm_kernel<128>;
   hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
   if (ks > 1) {
-    const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4;
+    const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4 + (p.colsum != nullptr ? p.M / 4 : 0);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, ks);
   }
   SRN_CHECK_LAUNCH();

@@ -206,17 +206,18 @@ def tn_workspace(device, nbytes):
 
 class TnGemmOp:
     """srn_tn_gemm (include/serenade_hip.h): out[z, m, j*N + n] = alpha * sum_{item,t} a[z,item,t,m] *
-    b[z,item,t*stride + shifts[j], n].  a / b / out: tensor or (tensor, element offset)."""
+    b[z,item,t*stride + shifts[j], n].  a / b / out: tensor or (tensor, element offset).  len_b (int32, per item): rows
+    of b at or past it read as zero; colsum (M,): alpha * the column sums of a (a conv's bias gradient), same launch."""
 
     __slots__ = ("p", "kw", "_fn", "_ws")
 
     def __init__(self, *, a, b, out, n_items, T_a, T_b, M, N, lda, ldb, ldc, shifts=(0,), stride=1, n_batch=1,
                  n_head=1, a_bs=0, a_hs=0, a_is=0, b_bs=0, b_hs=0, b_is=0, out_bs=0, out_hs=0, alpha=1.0, n_inner=1,
-                 a_is2=0, b_is2=0):
+                 a_is2=0, b_is2=0, len_b=None, colsum=None):
         self.kw = dict(a=a, b=b, out=out, n_items=n_items, T_a=T_a, T_b=T_b, M=M, N=N, lda=lda, ldb=ldb, ldc=ldc,
                        shifts=tuple(int(v) for v in shifts), stride=stride, n_batch=n_batch, n_head=n_head, a_bs=a_bs,
                        a_hs=a_hs, a_is=a_is, b_bs=b_bs, b_hs=b_hs, b_is=b_is, out_bs=out_bs, out_hs=out_hs, alpha=alpha,
-                       n_inner=n_inner, a_is2=a_is2, b_is2=b_is2)
+                       n_inner=n_inner, a_is2=a_is2, b_is2=b_is2, len_b=len_b, colsum=colsum)
         p = _lib.SrnTnGemmParams()
         p.n_batch, p.n_head, p.n_items, p.T_a, p.T_b = n_batch, n_head, n_items, T_a, T_b
         p.stride, p.n_shifts, p.M, p.N = stride, len(shifts), M, N
@@ -226,6 +227,9 @@ class TnGemmOp:
         p.b, p.b_bs, p.b_hs, p.b_is, p.ldb = _ptr(b), b_bs, b_hs, b_is, ldb
         p.out, p.out_bs, p.out_hs, p.ldc, p.alpha = _ptr(out), out_bs, out_hs, ldc, float(alpha)
         p.n_inner, p.a_is2, p.b_is2 = n_inner, a_is2, b_is2
+        if len_b is not None and len_b.dtype != torch.int32:
+            raise TypeError("TnGemmOp: len_b must be int32")
+        p.len_b, p.colsum = _ptr(len_b), _ptr(colsum)
         self._fn = _lib.lib().srn_tn_gemm
         need = int(_lib.lib().srn_tn_gemm_workspace_bytes(ctypes.byref(p)))
         self._ws = None

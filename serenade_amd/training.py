@@ -51,20 +51,23 @@ def _rup(n, m):
 #  conv / linear
 # =====================================================================================================================
 def _launch_conv(x, w, bias, y, taps, B, T_in, T_out, C, N, in_stride=1, out_t_stride=1, out_t_off=0, ld_out=None,
-                 out_bs=None, gn_partials=None):
+                 out_bs=None, gn_partials=None, len_in=None, len_out=None):
     ConvOp(in0=x, w=w, out=y, n_batch=B, T_in=T_in, T_out=T_out, C_in=C, N=N, in0_bs=T_in * C, ld_in0=C,
            ldw=w.shape[1], out_bs=(T_out * N if out_bs is None else out_bs), ld_out=(N if ld_out is None else ld_out),
            bias=bias, taps=taps, in_stride=in_stride, out_t_stride=out_t_stride, out_t_off=out_t_off,
-           gn_partials=gn_partials, precision=_lib.PREC_FP32)()
+           gn_partials=gn_partials, len_in=len_in, len_out=len_out, precision=_lib.PREC_FP32)()
 
 
 class _Conv(torch.autograd.Function):
     """y[b, t, :] = sum_j x[b, t * stride + taps[j], :] W_j^T + bias  (rows outside [0, T) read as zero).
     x (B, T, C) fp32 contiguous, C % 4 == 0; w packed (N, len(taps) * C), k-major; optional GroupNorm partial sums of
-    the output (32 x 32 tiles, conv epilogue) as a second, non-differentiable result."""
+    the output (32 x 32 tiles, conv epilogue) as a second, non-differentiable result.
+    lens (B,) int32 or None (stride 1 only): input rows t >= lens[b] count as zero -- the reference's `x * mask` in front
+    of its convs (decoder.py:66-101) without the multiply: the forward reads them as zero (len_in), dX's rows past the
+    length are stored as zero (len_out), and the weight gradient skips them (srn_tn_gemm's len_b)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, taps, stride, T_out, want_gn):
+    def forward(ctx, x, w, bias, taps, stride, T_out, want_gn, lens=None):
         _require_cuda(x, "training.conv1d")
         B, T, C = x.shape
         N = w.shape[0]
@@ -73,9 +76,10 @@ class _Conv(torch.autograd.Function):
         part = None
         if want_gn:
             part = torch.empty(B, (T_out + 31) // 32, N // 32, 2, device=x.device, dtype=torch.float32)
-        _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part)
+        assert lens is None or stride == 1
+        _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part, len_in=lens)
         ctx.save_for_backward(x, w)
-        ctx.taps, ctx.stride, ctx.has_bias = tuple(taps), stride, bias is not None
+        ctx.taps, ctx.stride, ctx.has_bias, ctx.lens = tuple(taps), stride, bias is not None, lens
         if want_gn:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -84,12 +88,13 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_):
         x, w = ctx.saved_tensors
-        taps, stride = ctx.taps, ctx.stride
+        taps, stride, lens = ctx.taps, ctx.stride, ctx.lens
         B, T, C = x.shape
         _, T_out, N = dy.shape
         nt = len(taps)
         dy = dy.contiguous()
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0]:
             # dgrad: dX[t] = sum_j dY[(t - taps[j]) / stride] W_j over the taps that divide -> a conv of dY with the
             # transposed weights Wd[c][j][n] = W[n][j][c]; with stride 2 one launch per output-row parity
@@ -97,7 +102,7 @@ class _Conv(torch.autograd.Function):
             _call("srn_transpose_ct", w, wd, nt, N, C, C, nt * C, N, nt * N)
             dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
             if stride == 1:
-                _launch_conv(dy, wd.view(C, nt * N), None, dx, [-o for o in taps], B, T_out, T, N, C)
+                _launch_conv(dy, wd.view(C, nt * N), None, dx, [-o for o in taps], B, T_out, T, N, C, len_out=lens)
             else:
                 for ph in range(stride):
                     sel = [j for j, o in enumerate(taps) if (ph - o) % stride == 0]
@@ -113,18 +118,22 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # wgrad: dW_j = sum_{b,t} dY[b,t,:]^T x[b, t*stride + taps[j], :] -- a contraction over time on operands
             # that are time-major as they lie: srn_tn_gemm (rows outside the item read as zero; time sliced over
-            # workgroups, slices added in order), straight into the packed (N, taps * C) layout
+            # workgroups, slices added in order), straight into the packed (N, taps * C) layout; the bias gradient (the
+            # column sums of dY) rides along in the same launch
             dw = torch.empty(N, nt * C, device=dy.device, dtype=torch.float32)
+            if want_db and N % 4 == 0:
+                db = torch.empty(N, device=dy.device, dtype=torch.float32)
             TnGemmOp(a=dy, b=x, out=dw, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=nt * C, shifts=taps,
-                     stride=stride, a_is=T_out * N, b_is=T * C)()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+                     stride=stride, a_is=T_out * N, b_is=T * C, len_b=lens, colsum=db)()
+        if want_db and db is None:
             db = _colsum(dy.reshape(-1, N))  # own kernel, not a torch reduction: see AdamW._grad_norm
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None):
+def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None, lens=None):
     """channels-last conv / linear over the HIP contraction kernel.  x (B, T, C) or (rows, C); w packed (N, k * C).
-    T_out (stride 1 only): number of output rows when the input was padded by the caller (taps >= 0, "valid" conv)."""
+    T_out (stride 1 only): number of output rows when the input was padded by the caller (taps >= 0, "valid" conv).
+    lens (B,) int32 (stride 1 only): conv of x with its rows past lens[b] zeroed (`x * mask`), see _Conv."""
     two_d = x.dim() == 2
     if two_d:
         x = x.unsqueeze(0)
@@ -136,7 +145,7 @@ def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None):
     else:  # torch Conv1d with padding (k - 1) / 2: taps -p .. p
         p = -min(taps)
         T_out = (T + 2 * p - (len(taps) - 1) - 1) // stride + 1
-    out = _Conv.apply(x, w, bias, tuple(int(t) for t in taps), int(stride), int(T_out), bool(want_gn))
+    out = _Conv.apply(x, w, bias, tuple(int(t) for t in taps), int(stride), int(T_out), bool(want_gn), lens)
     if two_d:
         return out.squeeze(0)
     return out
@@ -642,7 +651,7 @@ class Estimator:
     def _block1d(self, p, x, maskf, lens, c_pad=None):
         """Block1D (decoder.py:66-77): conv k3 of the masked input -> GroupNorm(8) -> Mish -> mask"""
         w = pack_conv(self.params[p + "block.0.weight"], c_pad)
-        h, part = conv1d(x * maskf, w, self.params[p + "block.0.bias"], ops.conv_taps(3), want_gn=True)
+        h, part = conv1d(x, w, self.params[p + "block.0.bias"], ops.conv_taps(3), want_gn=True, lens=lens)
         return gn_mish(h, part, self.params[p + "block.1.weight"], self.params[p + "block.1.bias"], lens, self.GROUPS)
 
     def _resnet(self, p, x, maskf, lens, temb, spk, c_pad=None):
@@ -650,7 +659,8 @@ class Estimator:
         h = self._block1d(p + "block1.", x, maskf, lens, c_pad)
         h = _AddRowBias.apply(h, self._lin(F.mish(temb), p + "mlp.1"))
         h = self._block1d(p + "block2.", h, maskf, lens)
-        out = h + conv1d(x * maskf, pack_conv(self.params[p + "res_conv.weight"], c_pad), self.params[p + "res_conv.bias"])
+        out = h + conv1d(x, pack_conv(self.params[p + "res_conv.weight"], c_pad), self.params[p + "res_conv.bias"],
+                         lens=lens)
         scale = self._lin(spk, p + "speaker_projection.W_scale")
         shift = self._lin(spk, p + "speaker_projection.W_bias")
         return row_ln(out, scale, shift)
@@ -696,7 +706,7 @@ class Estimator:
             if p + "2.conv.weight" in P:
                 h = conv1d(h * mf, pack_conv(P[p + "2.conv.weight"]), P[p + "2.conv.bias"], ops.conv_taps(3), stride=2)
             else:
-                h = conv1d(h * mf, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3))
+                h = conv1d(h, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3), lens=lens)
             masks.append(m[:, ::2])
         masks = masks[:-1]
         m = masks[-1]
@@ -715,15 +725,14 @@ class Estimator:
             h = self._tfm(p + "1.0.", h, lens)
             if p + "2.conv.weight" in P:
                 # ConvTranspose1d(k 4, stride 2, padding 1): two output phases, each a 2-tap conv of the input
-                hm = h * mf
                 ys = []
                 for taps, wp in _convtranspose_phases(P[p + "2.conv.weight"], 2, 1):
-                    ys.append(conv1d(hm, wp, P[p + "2.conv.bias"], taps))
+                    ys.append(conv1d(h, wp, P[p + "2.conv.bias"], taps, lens=lens))
                 h = torch.stack(ys, dim=2).reshape(B, -1, ys[0].shape[-1])
             else:
-                h = conv1d(h * mf, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3))
+                h = conv1d(h, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3), lens=lens)
         h = self._block1d("final_block.", h, mf, lens)
-        out = conv1d(h * mf, pack_conv(P["final_proj.weight"]), P["final_proj.bias"])
+        out = conv1d(h, pack_conv(P["final_proj.weight"]), P["final_proj.bias"], lens=lens)
         return (out * maskb.unsqueeze(-1).to(torch.float32)).transpose(1, 2)
 
     __call__ = forward

@@ -504,6 +504,14 @@ def emul_tn_gemm(kw):
     b, ob = _flat(g("b"))
     out, oo = _flat(g("out"))
     M, N, T_a, T_b, stride = g("M"), g("N"), g("T_a"), g("T_b"), g("stride")
+    len_b, colsum = g("len_b"), g("colsum")
+    if colsum is not None:
+        assert g("n_batch") == 1 and g("n_head") == 1 and M % 4 == 0, "colsum: one problem, M % 4 == 0"
+        cs = torch.zeros(M, dtype=torch.float64)
+        for it in range(g("n_items")):
+            i1, i2 = divmod(it, max(1, g("n_inner", 1)))
+            cs += torch.as_strided(a, (T_a, M), (g("lda"), 1), oa + i1 * g("a_is") + i2 * g("a_is2", 0)).double().sum(0)
+        colsum.view(-1)[:M] = (cs * g("alpha")).float()
     for zb in range(g("n_batch")):
         for zh in range(g("n_head")):
             for j, sh in enumerate(g("shifts")):
@@ -515,7 +523,11 @@ def emul_tn_gemm(kw):
                     b0 = ob + zb * g("b_bs") + zh * g("b_hs") + i1 * g("b_is") + i2 * g("b_is2", 0)
                     am = torch.as_strided(a, (T_a, M), (g("lda"), 1), a0).double()
                     tb = torch.arange(T_a) * stride + sh
-                    ok = (tb >= 0) & (tb < T_b)
+                    end = T_b
+                    if len_b is not None:
+                        assert ninner == 1, "len_b: one-level items"
+                        end = min(T_b, int(len_b.view(-1)[zb * g("n_items") + it]))
+                    ok = (tb >= 0) & (tb < end)
                     rows = torch.as_strided(b, (T_b, N), (g("ldb"), 1), b0).double()[tb.clamp(0, T_b - 1)]
                     acc += am.t() @ (rows * ok[:, None])
                 o0 = oo + zb * g("out_bs") + zh * g("out_hs") + j * N
@@ -544,7 +556,7 @@ class installed:
         def tn_init(self_, **kw):  # no library call (workspace query) on the CPU
             kw.setdefault("shifts", (0,))
             for k, v in dict(stride=1, n_batch=1, n_head=1, a_bs=0, a_hs=0, a_is=0, b_bs=0, b_hs=0, b_is=0, out_bs=0,
-                             out_hs=0, alpha=1.0, n_inner=1, a_is2=0, b_is2=0).items():
+                             out_hs=0, alpha=1.0, n_inner=1, a_is2=0, b_is2=0, len_b=None, colsum=None).items():
                 kw.setdefault(k, v)
             self_.kw = kw
         ops.TnGemmOp.__init__ = tn_init

@@ -408,24 +408,36 @@ def test_tn_gemm_against_fp64(dev, case):
                                            "wgrad_valid": (2, 70, 64, 80, (0, 2, 4, 6), 1, 64),
                                            "wgrad_tiny_k": (3, 1, 2048, 512, (0,), 1, 1)}[case]
         x, dy = r(B, T, C), r(B, T_out, N)
-        dw = torch.full((N, len(taps) * C), float("nan"), device=dev)
-        TnGemmOp(a=dy, b=x, out=dw, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C, shifts=taps,
-                 stride=stride, a_is=T_out * N, b_is=T * C)()
-        ref = torch.zeros(N, len(taps), C, dtype=torch.float64)
-        xd, dyd = x.double().cpu(), dy.double().cpu()
-        for j, o in enumerate(taps):
-            for t in range(T_out):
-                tb = t * stride + o
-                if 0 <= tb < T:
-                    ref[:, j] += torch.einsum("bn,bc->nc", dyd[:, t], xd[:, tb])
-        got = dw.cpu().double().view(N, len(taps), C)
-        assert torch.isfinite(got).all()
-        assert (got - ref).abs().max() < 2e-5 * ref.abs().max(), case
-        # bit-reproducible (slices are added in order)
-        dw2 = torch.empty_like(dw)
-        TnGemmOp(a=dy, b=x, out=dw2, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C,
-                 shifts=taps, stride=stride, a_is=T_out * N, b_is=T * C)()
-        assert torch.equal(dw, dw2)
+        # second pass: the same contraction with per-item lengths on x (rows past them count as zero) and the bias
+        # gradient (column sums of dY) riding along
+        lens_cpu = torch.tensor([max(1, T - 7 * i - 3) for i in range(B)], dtype=torch.int32)
+        for lens in (None, lens_cpu.to(dev)):
+            dw = torch.full((N, len(taps) * C), float("nan"), device=dev)
+            db = None if lens is None else torch.full((N,), float("nan"), device=dev)
+            kw = dict(a=dy, b=x, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C, shifts=taps,
+                      stride=stride, a_is=T_out * N, b_is=T * C, len_b=lens, colsum=db)
+            TnGemmOp(out=dw, **kw)()
+            ref = torch.zeros(N, len(taps), C, dtype=torch.float64)
+            xd, dyd = x.double().cpu(), dy.double().cpu()
+            if lens is not None:
+                xd = xd * (torch.arange(T)[None, :, None] < lens_cpu[:, None, None])
+            for j, o in enumerate(taps):
+                for t in range(T_out):
+                    tb = t * stride + o
+                    if 0 <= tb < T:
+                        ref[:, j] += torch.einsum("bn,bc->nc", dyd[:, t], xd[:, tb])
+            got = dw.cpu().double().view(N, len(taps), C)
+            assert torch.isfinite(got).all()
+            assert (got - ref).abs().max() < 2e-5 * ref.abs().max(), case
+            if db is not None:
+                cs = dyd.sum((0, 1))
+                assert (db.cpu().double() - cs).abs().max() < 2e-5 * max(1.0, cs.abs().max()), case
+            # bit-reproducible (slices are added in order)
+            dw2 = torch.empty_like(dw)
+            db2 = None if db is None else torch.empty_like(db)
+            kw["colsum"] = db2
+            TnGemmOp(out=dw2, **kw)()
+            assert torch.equal(dw, dw2) and (db is None or torch.equal(db, db2))
     else:
         B, H, L, hd = (2, 4, 256, 64) if case == "attn" else (2, 2, 203, 32)
         Lp = (L + 31) // 32 * 32
