@@ -181,6 +181,23 @@ int srn_scatter_rows(const float* src, int64_t src_bs, int ld_src, float* dst, i
 /* (B, C, T) <-> (B, T, C) transposes at the API edge (reference tensors are (B, C, T); decoder.py:405-467). */
 int srn_transpose_ct(const float* src, float* dst, int B, int R, int Cc, int64_t src_bs, int ld_src, int64_t dst_bs,
                      int ld_dst, void* stream);
+/* Many such transposes in ONE launch (the table travels in the kernel arguments: capturable): entry e does
+ * dst_e[b][c][r] = src_e[b][r][c] for b < B, r < R, c < Cc.  The training step re-lays every conv / linear weight
+ * once per step (torch (N, C, k) -> the k-major rows srn_conv_gemm reads, and W^T for the input gradient; what autograd
+ * does implicitly for decoder.py's Conv1d / Linear under trainers/ssc.py:57-96): ~140 launches of a few microseconds
+ * each when issued one by one. */
+#define SRN_TR_LIST_MAX 40
+typedef struct SrnTransposeList {
+  int32_t n;
+  int32_t pad_;
+  const float* src[SRN_TR_LIST_MAX];
+  float* dst[SRN_TR_LIST_MAX];
+  int64_t src_bs[SRN_TR_LIST_MAX], dst_bs[SRN_TR_LIST_MAX];
+  int32_t B[SRN_TR_LIST_MAX], R[SRN_TR_LIST_MAX], Cc[SRN_TR_LIST_MAX];
+  int32_t ld_src[SRN_TR_LIST_MAX], ld_dst[SRN_TR_LIST_MAX];
+  int32_t first_block[SRN_TR_LIST_MAX + 1];  /* filled by the library */
+} SrnTransposeList;
+int srn_transpose_multi(const SrnTransposeList* list, void* stream);
 
 /* y = (x * a[c] + b[c] - c[c]) / d[c] (Vocoder.decode normalisation, vocoder.py:52-56); x, y (rows, C). */
 int srn_renorm(const float* x, const float* trg_scale, const float* trg_mean, const float* voc_mean,

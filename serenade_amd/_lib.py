@@ -68,6 +68,17 @@ class SrnWorldParams(ctypes.Structure):
     ]
 
 
+SRN_TR_LIST_MAX = 40
+
+
+class SrnTransposeList(ctypes.Structure):
+    _fields_ = [("n", c_int32), ("pad_", c_int32), ("src", c_void_p * SRN_TR_LIST_MAX), ("dst", c_void_p * SRN_TR_LIST_MAX),
+                ("src_bs", c_int64 * SRN_TR_LIST_MAX), ("dst_bs", c_int64 * SRN_TR_LIST_MAX),
+                ("B", c_int32 * SRN_TR_LIST_MAX), ("R", c_int32 * SRN_TR_LIST_MAX), ("Cc", c_int32 * SRN_TR_LIST_MAX),
+                ("ld_src", c_int32 * SRN_TR_LIST_MAX), ("ld_dst", c_int32 * SRN_TR_LIST_MAX),
+                ("first_block", c_int32 * (SRN_TR_LIST_MAX + 1))]
+
+
 class SrnTnGemmParams(ctypes.Structure):
     _fields_ = [
         ("n_batch", c_int32), ("n_head", c_int32), ("n_items", c_int32), ("T_a", c_int32), ("T_b", c_int32),
@@ -105,6 +116,7 @@ _SIGS = {
     "srn_sinusoidal_emb": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),
     "srn_copy_channels": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_transpose_ct": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, _P]),
+    "srn_transpose_multi": (c_int, [POINTER(SrnTransposeList), _P]),
     "srn_renorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "srn_out_conv_tanh": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "srn_pd_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),

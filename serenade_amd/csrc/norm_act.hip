@@ -327,6 +327,45 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// the same for a table of problems: a block finds its entry by the prefix of block counts, then its (b, row tile,
+// column tile).  Entries with a narrow side (a conv's k = 3 taps) would waste 29 of 32 tile columns: they go element
+// by element instead (1024 dst elements per block, reads strided through L2).
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const SrnTransposeList L) {
+  __shared__ float tile[32][33];
+  int e = 0;
+  while (e + 1 < L.n && (int)blockIdx.x >= L.first_block[e + 1]) ++e;
+  const int blk = blockIdx.x - L.first_block[e];
+  const float* __restrict__ src = L.src[e];
+  float* __restrict__ dst = L.dst[e];
+  const int R = L.R[e], Cc = L.Cc[e], ld_src = L.ld_src[e], ld_dst = L.ld_dst[e];
+  const int64_t src_bs = L.src_bs[e], dst_bs = L.dst_bs[e];
+  if (R < 16 || Cc < 16) {
+    const int64_t per_b = (int64_t)R * Cc, total = per_b * L.B[e];
+    for (int i = 0; i < 4; ++i) {
+      const int64_t idx = (int64_t)blk * 1024 + i * 256 + threadIdx.x;  // dst order: b, c, r
+      if (idx >= total) return;
+      const int b = (int)(idx / per_b);
+      const int rem = (int)(idx - (int64_t)b * per_b);
+      const int c = rem / R, r = rem - c * R;
+      dst[b * dst_bs + (int64_t)c * ld_dst + r] = src[b * src_bs + (int64_t)r * ld_src + c];
+    }
+    return;
+  }
+  const int tc = (Cc + 31) / 32, tr = (R + 31) / 32;
+  const int b = blk / (tc * tr), t = blk - b * tc * tr;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? src[b * src_bs + (int64_t)r * ld_src + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) dst[b * dst_bs + (int64_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+
 __global__ void renorm_kernel(const float* __restrict__ x, const float* __restrict__ ts, const float* __restrict__ tm,
                               const float* __restrict__ vm, const float* __restrict__ vs, float* __restrict__ y,
                               int64_t total, int C) {
@@ -509,6 +548,25 @@ extern "C" int srn_transpose_ct(const float* src, float* dst, int B, int R, int 
   dim3 grid((Cc + 31) / 32, (R + 31) / 32, B);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc, src_bs, ld_src,
                      dst_bs, ld_dst);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_transpose_multi(const SrnTransposeList* list, void* stream) {
+  SRN_CHECK_ARG(list != nullptr && list->n > 0 && list->n <= SRN_TR_LIST_MAX, "transpose_multi: bad list");
+  SrnTransposeList L = *list;
+  int64_t blocks = 0;
+  for (int e = 0; e < L.n; ++e) {
+    SRN_CHECK_ARG(L.src[e] && L.dst[e] && L.B[e] > 0 && L.R[e] > 0 && L.Cc[e] > 0 && L.ld_src[e] >= L.Cc[e] &&
+                      L.ld_dst[e] >= L.R[e],
+                  "transpose_multi: entry %d: bad pointers / sizes / leading dimensions", e);
+    L.first_block[e] = (int32_t)blocks;
+    if (L.R[e] < 16 || L.Cc[e] < 16) blocks += ((int64_t)L.B[e] * L.R[e] * L.Cc[e] + 1023) / 1024;
+    else blocks += (int64_t)L.B[e] * ((L.R[e] + 31) / 32) * ((L.Cc[e] + 31) / 32);
+    SRN_CHECK_ARG(blocks < (1ll << 31), "transpose_multi: grid too large");
+  }
+  L.first_block[L.n] = (int32_t)blocks;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, L);
   SRN_CHECK_LAUNCH();
   return 0;
 }

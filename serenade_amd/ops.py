@@ -192,6 +192,32 @@ class MultiCopyOp:
             check(self._fn(ctypes.byref(lst), _ptr(self.dst), st), "srn_multi_copy")
 
 
+class TransposeMultiOp:
+    """srn_transpose_multi: a table of batched 2-D transposes as one launch per 40 entries.  entries: (src, dst, B, R,
+    Cc, src_bs, ld_src, dst_bs, ld_dst) with dst[b][c][r] = src[b][r][c]; src / dst: tensor or (tensor, element offset)."""
+
+    __slots__ = ("entries", "_lists", "_fn")
+
+    def __init__(self, entries):
+        self.entries = list(entries)
+        self._fn = _lib.lib().srn_transpose_multi
+        self._lists = []
+        for i0 in range(0, len(self.entries), _lib.SRN_TR_LIST_MAX):
+            lst = _lib.SrnTransposeList()
+            chunk = self.entries[i0:i0 + _lib.SRN_TR_LIST_MAX]
+            lst.n = len(chunk)
+            for j, (src, dst, B, R, Cc, src_bs, ld_src, dst_bs, ld_dst) in enumerate(chunk):
+                lst.src[j], lst.dst[j] = _ptr(src), _ptr(dst)
+                lst.B[j], lst.R[j], lst.Cc[j] = B, R, Cc
+                lst.src_bs[j], lst.ld_src[j], lst.dst_bs[j], lst.ld_dst[j] = src_bs, ld_src, dst_bs, ld_dst
+            self._lists.append(lst)
+
+    def __call__(self, stream=None):
+        st = stream if stream is not None else _stream()
+        for lst in self._lists:
+            check(self._fn(ctypes.byref(lst), st), "srn_transpose_multi")
+
+
 _TN_WS = {}
 
 

@@ -67,7 +67,7 @@ class _Conv(torch.autograd.Function):
     length are stored as zero (len_out), and the weight gradient skips them (srn_tn_gemm's len_b)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, taps, stride, T_out, want_gn, lens=None):
+    def forward(ctx, x, w, bias, taps, stride, T_out, want_gn, lens=None, wd=None):
         _require_cuda(x, "training.conv1d")
         B, T, C = x.shape
         N = w.shape[0]
@@ -79,7 +79,7 @@ class _Conv(torch.autograd.Function):
         assert lens is None or stride == 1
         _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part, len_in=lens)
         ctx.save_for_backward(x, w)
-        ctx.taps, ctx.stride, ctx.has_bias, ctx.lens = tuple(taps), stride, bias is not None, lens
+        ctx.taps, ctx.stride, ctx.has_bias, ctx.lens, ctx.wd = tuple(taps), stride, bias is not None, lens, wd
         if want_gn:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -98,8 +98,11 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dgrad: dX[t] = sum_j dY[(t - taps[j]) / stride] W_j over the taps that divide -> a conv of dY with the
             # transposed weights Wd[c][j][n] = W[n][j][c]; with stride 2 one launch per output-row parity
-            wd = torch.empty(C, nt, N, device=dy.device, dtype=torch.float32)  # LDS tile transposes, one batch per tap
-            _call("srn_transpose_ct", w, wd, nt, N, C, C, nt * C, N, nt * N)
+            if ctx.wd is not None:  # re-laid once for the whole step (Estimator._relay)
+                wd = ctx.wd.view(C, nt, N)
+            else:
+                wd = torch.empty(C, nt, N, device=dy.device, dtype=torch.float32)  # LDS tile transposes, one batch per tap
+                _call("srn_transpose_ct", w, wd, nt, N, C, C, nt * C, N, nt * N)
             dx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
             if stride == 1:
                 _launch_conv(dy, wd.view(C, nt * N), None, dx, [-o for o in taps], B, T_out, T, N, C, len_out=lens)
@@ -127,13 +130,15 @@ class _Conv(torch.autograd.Function):
                      stride=stride, a_is=T_out * N, b_is=T * C, len_b=lens, colsum=db)()
         if want_db and db is None:
             db = _colsum(dy.reshape(-1, N))  # own kernel, not a torch reduction: see AdamW._grad_norm
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None, lens=None):
+def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None, lens=None, wd=None):
     """channels-last conv / linear over the HIP contraction kernel.  x (B, T, C) or (rows, C); w packed (N, k * C).
     T_out (stride 1 only): number of output rows when the input was padded by the caller (taps >= 0, "valid" conv).
-    lens (B,) int32 (stride 1 only): conv of x with its rows past lens[b] zeroed (`x * mask`), see _Conv."""
+    lens (B,) int32 (stride 1 only): conv of x with its rows past lens[b] zeroed (`x * mask`), see _Conv.
+    wd: the weights already laid out for the input gradient, (C, taps * N) with wd[c, j * N + n] = w[n, j * C + c], when
+    the caller keeps them (Estimator._relay); made on the fly otherwise."""
     two_d = x.dim() == 2
     if two_d:
         x = x.unsqueeze(0)
@@ -145,7 +150,7 @@ def conv1d(x, w, bias, taps=(0,), stride=1, want_gn=False, T_out=None, lens=None
     else:  # torch Conv1d with padding (k - 1) / 2: taps -p .. p
         p = -min(taps)
         T_out = (T + 2 * p - (len(taps) - 1) - 1) // stride + 1
-    out = _Conv.apply(x, w, bias, tuple(int(t) for t in taps), int(stride), int(T_out), bool(want_gn), lens)
+    out = _Conv.apply(x, w, bias, tuple(int(t) for t in taps), int(stride), int(T_out), bool(want_gn), lens, wd)
     if two_d:
         return out.squeeze(0)
     return out
@@ -197,6 +202,37 @@ class _PackConv(torch.autograd.Function):
         dw = torch.empty(n, c, k, device=dp.device, dtype=torch.float32)
         _call("srn_transpose_ct", dp.contiguous(), dw, n, k, c, k * c_pad, c_pad, c * k, k)
         return dw, None
+
+
+class _PackAll(torch.autograd.Function):
+    """Every conv weight of the estimator (N, C, k) -> (N, k * C_pad) in ONE launch, into buffers the estimator keeps
+    (Estimator._relay), together with W^T of every conv / linear for the input gradients; backward: the packed gradients
+    back to (N, C, k), one launch again.  Issued one by one these were ~140 launches of a few microseconds per step."""
+
+    @staticmethod
+    def forward(ctx, est, *weights):
+        for op in est._relay_ops:
+            op()
+        ctx.est = est
+        return tuple(est._pk[name].detach() for name in est._pack_names)  # fresh aliases: apply() marks its outputs
+
+    @staticmethod
+    def backward(ctx, *dps):
+        est = ctx.est
+        outs, entries = [], []
+        for name, dp in zip(est._pack_names, dps):
+            n, c, k = est.params[name].shape
+            if dp is None:
+                outs.append(None)
+                continue
+            c_pad = est._pk[name].shape[1] // k
+            dp = dp.contiguous()
+            dw = torch.empty(n, c, k, device=dp.device, dtype=torch.float32)
+            entries.append((dp, dw, n, k, c, k * c_pad, c_pad, c * k, k))
+            outs.append(dw)
+        if entries:
+            ops.TransposeMultiOp(entries)()
+        return (None, *outs)
 
 
 def pack_conv(w, c_pad=None):
@@ -631,12 +667,69 @@ class Estimator:
         self.n_down = sum(1 for k in names if k.startswith("down_blocks.") and k.endswith(".0.mlp.1.weight"))
         self.n_mid = sum(1 for k in names if k.startswith("mid_blocks.") and k.endswith(".0.mlp.1.weight"))
         self.n_up = sum(1 for k in names if k.startswith("up_blocks.") and k.endswith(".0.mlp.1.weight"))
+        self._plan_relay()
 
     def state_dict(self):
         return {k: v.detach().clone() for k, v in self.params.items()}
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def _plan_relay(self):
+        """What every step re-lays of the weights, planned once: conv weights (N, C, k) -> packed (N, k * C_pad)
+        (`self._pk`, the differentiable outputs of _PackAll) and, for every conv / linear, W^T for the input gradient
+        (`self._wd[name]`: (C_pad, k * N); q | k | v side by side for the fused projection).  Buffers are allocated here
+        (pad columns stay zero) and the transposes are two prebuilt srn_transpose_multi tables: parameters first, then
+        the transposes that read the packed buffers."""
+        P, dev = self.params, self.device
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        cin0 = P["down_blocks.0.0.block1.block.0.weight"].shape[1]
+        self._pk, self._wd, self._pack_names = {}, {}, []
+        first, second = [], []
+        for name, w in P.items():
+            if not name.endswith(".weight") or w.dim() not in (2, 3):
+                continue
+            if name.startswith("up_blocks.") and name.endswith("2.conv.weight"):
+                continue  # ConvTranspose1d: re-laid per output phase by _convtranspose_phases
+            if name.startswith("time_mlp.linear_1"):
+                continue  # its input is padded on the fly (242 -> 244 columns)
+            if any(t in name for t in (".to_q.", ".to_k.", ".to_v.")):
+                continue  # the fused projection, below
+            if w.dim() == 2 and w.shape[0] * w.shape[1] >= 64:
+                n, c = w.shape
+                if ".norm" in name:
+                    continue
+                self._wd[name] = z(c, n)
+                first.append((w, self._wd[name], 1, n, c, 0, c, 0, n))
+            elif w.dim() == 3:
+                n, c, k = w.shape
+                c_pad = _rup(c, 32) if name.startswith("down_blocks.0.0.") and c == cin0 else c
+                self._wd[name] = z(c_pad, k * n)
+                if k == 1 and c_pad == c:  # pack_conv is a view
+                    first.append((w, self._wd[name], 1, n, c, 0, c, 0, n))
+                    continue
+                self._pk[name] = z(n, k * c_pad)
+                self._pack_names.append(name)
+                first.append((w, self._pk[name], n, c, k, c * k, k, k * c_pad, c_pad))
+                second.append((self._pk[name], self._wd[name], k, n, c_pad, c_pad, k * c_pad, n, k * n))
+        for name in [k for k in P if k.endswith("attn1.to_q.weight")]:
+            pre = name[:-len("to_q.weight")]
+            ws = [P[pre + t + ".weight"] for t in ("to_q", "to_k", "to_v")]
+            inner, c = ws[0].shape
+            wd = z(c, 3 * inner)
+            self._wd[pre + "qkv"] = wd
+            for i, w in enumerate(ws):
+                first.append((w, (wd, i * inner), 1, inner, c, 0, c, 0, 3 * inner))
+        self._relay_ops = [ops.TransposeMultiOp(first), ops.TransposeMultiOp(second)]
+
+    def _relay(self):
+        """once per forward: packed conv weights (differentiable) + the input-gradient layouts (constants of the step)"""
+        packed = _PackAll.apply(self, *[self.params[n] for n in self._pack_names])
+        self._pkd = dict(zip(self._pack_names, packed))
+
+    def _packed(self, name, c_pad=None):
+        w = self._pkd.get(name)
+        return w if w is not None else pack_conv(self.params[name], c_pad)
 
     def _drop(self, x):
         return F.dropout(x, self.dropout, True) if self.dropout > 0.0 else x
@@ -646,12 +739,14 @@ class Estimator:
         w = self.params[name + ".weight"]
         if c_pad is not None and c_pad > w.shape[1]:
             w = F.pad(w, (0, c_pad - w.shape[1]))
-        return conv1d(x, w, self.params[name + ".bias"] if bias else None)
+        wd = self._wd.get(name + ".weight") if c_pad is None else None
+        return conv1d(x, w, self.params[name + ".bias"] if bias else None, wd=wd)
 
     def _block1d(self, p, x, maskf, lens, c_pad=None):
         """Block1D (decoder.py:66-77): conv k3 of the masked input -> GroupNorm(8) -> Mish -> mask"""
-        w = pack_conv(self.params[p + "block.0.weight"], c_pad)
-        h, part = conv1d(x, w, self.params[p + "block.0.bias"], ops.conv_taps(3), want_gn=True, lens=lens)
+        w = self._packed(p + "block.0.weight", c_pad)
+        h, part = conv1d(x, w, self.params[p + "block.0.bias"], ops.conv_taps(3), want_gn=True, lens=lens,
+                         wd=self._wd.get(p + "block.0.weight"))
         return gn_mish(h, part, self.params[p + "block.1.weight"], self.params[p + "block.1.bias"], lens, self.GROUPS)
 
     def _resnet(self, p, x, maskf, lens, temb, spk, c_pad=None):
@@ -659,8 +754,8 @@ class Estimator:
         h = self._block1d(p + "block1.", x, maskf, lens, c_pad)
         h = _AddRowBias.apply(h, self._lin(F.mish(temb), p + "mlp.1"))
         h = self._block1d(p + "block2.", h, maskf, lens)
-        out = h + conv1d(x, pack_conv(self.params[p + "res_conv.weight"], c_pad), self.params[p + "res_conv.bias"],
-                         lens=lens)
+        out = h + conv1d(x, self._packed(p + "res_conv.weight", c_pad), self.params[p + "res_conv.bias"], lens=lens,
+                         wd=self._wd.get(p + "res_conv.weight"))
         scale = self._lin(spk, p + "speaker_projection.W_scale")
         shift = self._lin(spk, p + "speaker_projection.W_bias")
         return row_ln(out, scale, shift)
@@ -671,15 +766,16 @@ class Estimator:
         P = self.params
         n = row_ln(x, P[p + "norm1.weight"], P[p + "norm1.bias"])
         wqkv = torch.cat([P[p + "attn1.to_q.weight"], P[p + "attn1.to_k.weight"], P[p + "attn1.to_v.weight"]], dim=0)
-        o = attention_core(conv1d(n, wqkv, None), lens, self.N_HEAD)
-        x = self._drop(conv1d(o, P[p + "attn1.to_out.0.weight"], P[p + "attn1.to_out.0.bias"])) + x
+        o = attention_core(conv1d(n, wqkv, None, wd=self._wd.get(p + "attn1.qkv")), lens, self.N_HEAD)
+        x = self._drop(self._lin(o, p + "attn1.to_out.0")) + x
         n = row_ln(x, P[p + "norm3.weight"], P[p + "norm3.bias"])
-        a = self._drop(geglu(conv1d(n, P[p + "ff.net.0.proj.weight"], P[p + "ff.net.0.proj.bias"])))
-        return conv1d(a, P[p + "ff.net.2.weight"], P[p + "ff.net.2.bias"]) + x
+        a = self._drop(geglu(self._lin(n, p + "ff.net.0.proj")))
+        return self._lin(a, p + "ff.net.2") + x
 
     def forward(self, x, mask, mu, t, spks):
         _require_cuda(x, "Estimator.forward")
         P = self.params
+        self._relay()
         B, _, L = x.shape
         maskb = mask.reshape(B, L) > 0
         h = torch.cat([x, mu], dim=1).transpose(1, 2)  # (B, L, 242) channels-last
@@ -704,9 +800,11 @@ class Estimator:
             h = self._tfm(p + "1.0.", h, lens)
             hiddens.append(h)
             if p + "2.conv.weight" in P:
-                h = conv1d(h * mf, pack_conv(P[p + "2.conv.weight"]), P[p + "2.conv.bias"], ops.conv_taps(3), stride=2)
+                h = conv1d(h * mf, self._packed(p + "2.conv.weight"), P[p + "2.conv.bias"], ops.conv_taps(3), stride=2,
+                           wd=self._wd.get(p + "2.conv.weight"))
             else:
-                h = conv1d(h, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3), lens=lens)
+                h = conv1d(h, self._packed(p + "2.weight"), P[p + "2.bias"], ops.conv_taps(3), lens=lens,
+                           wd=self._wd.get(p + "2.weight"))
             masks.append(m[:, ::2])
         masks = masks[:-1]
         m = masks[-1]
@@ -730,9 +828,11 @@ class Estimator:
                     ys.append(conv1d(h, wp, P[p + "2.conv.bias"], taps, lens=lens))
                 h = torch.stack(ys, dim=2).reshape(B, -1, ys[0].shape[-1])
             else:
-                h = conv1d(h, pack_conv(P[p + "2.weight"]), P[p + "2.bias"], ops.conv_taps(3), lens=lens)
+                h = conv1d(h, self._packed(p + "2.weight"), P[p + "2.bias"], ops.conv_taps(3), lens=lens,
+                           wd=self._wd.get(p + "2.weight"))
         h = self._block1d("final_block.", h, mf, lens)
-        out = conv1d(h, pack_conv(P["final_proj.weight"]), P["final_proj.bias"], lens=lens)
+        out = conv1d(h, self._packed("final_proj.weight"), P["final_proj.bias"], lens=lens,
+                     wd=self._wd.get("final_proj.weight"))
         return (out * maskb.unsqueeze(-1).to(torch.float32)).transpose(1, 2)
 
     __call__ = forward

@@ -540,6 +540,15 @@ def emul_multi_copy(self_, stream=None):
         flat[o:o + t.numel()] = t.reshape(-1)
 
 
+def emul_transpose_multi(self_, stream=None):
+    """executable spec of srn_transpose_multi: entry e does dst[b][c][r] = src[b][r][c]"""
+    for src, dst, B, R, Cc, sbs, lds, dbs, ldd in self_.entries:
+        sf, df = _v(src), _v(dst)
+        rr, cc = torch.arange(R).unsqueeze(1), torch.arange(Cc).unsqueeze(0)
+        for b in range(B):
+            df[b * dbs + cc * ldd + rr] = sf[b * sbs + rr * lds + cc]
+
+
 class installed:
     """context manager: route every op through the emulator and lift the CUDA-only guard"""
 
@@ -550,6 +559,8 @@ class installed:
                        ops.ResUnitOp.__call__)
         self._saved_mc = ops.MultiCopyOp.__call__
         ops.MultiCopyOp.__call__ = emul_multi_copy
+        self._saved_tm = ops.TransposeMultiOp.__call__
+        ops.TransposeMultiOp.__call__ = emul_transpose_multi
         self._saved_tn = (ops.TnGemmOp.__call__, ops.TnGemmOp.__init__)
         ops.TnGemmOp.__call__ = lambda self_, stream=None: emul_tn_gemm(self_.kw)
 
@@ -570,6 +581,7 @@ class installed:
     def __exit__(self, *exc):
         ops.ConvOp.__call__, ops.CallOp.__call__, guards, ops.ResUnitOp.__call__ = self._saved
         ops.MultiCopyOp.__call__ = self._saved_mc
+        ops.TransposeMultiOp.__call__ = self._saved_tm
         ops.TnGemmOp.__call__, ops.TnGemmOp.__init__ = self._saved_tn
         for m, g in zip(self._mods, guards):
             m._require_cuda = g

@@ -43,7 +43,7 @@ def test_error_reporting_without_gpu(lib):
     assert b"null in0" in lib.srn_last_error()
 
 
-@pytest.mark.parametrize("name", ["SrnConvParams", "SrnResUnitParams", "SrnCopyList", "SrnWorldParams", "SrnExcitationParams", "SrnTnGemmParams"])
+@pytest.mark.parametrize("name", ["SrnConvParams", "SrnResUnitParams", "SrnCopyList", "SrnWorldParams", "SrnExcitationParams", "SrnTnGemmParams", "SrnTransposeList"])
 def test_struct_layout_matches_c(tmp_path, name):
     cls = getattr(_lib, name)
     fields = [f[0] for f in cls._fields_]

@@ -103,7 +103,7 @@ def main():
     g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in d.items()}
     mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"], g["ref_logmel"],
                           g["ref_midi"], g["ref_lft"], noise=g["z"])
-    voc.decode_batch(mel)
+    voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))
     torch.cuda.synchronize()
     pl = model.cfm_decoder.estimator.plan(B, T + Tr, 10, euler=True)
     if "--sweep" in sys.argv:
