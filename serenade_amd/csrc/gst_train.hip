@@ -19,34 +19,56 @@ namespace {
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
 // rows per partial-sum chunk: at most ~256 chunks, so the finishing kernel's ordered sum stays short
 __host__ __device__ inline int64_t bn_rows_per_chunk(int64_t R) { return R <= 256 * 16 ? 16 : (R + 255) / 256; }
-// (bn_partial_kernel: one thread per channel walks a chunk's rows; bn_finish_kernel adds the chunks)
+// (bn_partial_kernel: a workgroup takes up to 256 channels of one chunk; with fewer channels -- the GST's 32 .. 128 --
+// the spare threads take further rows of the chunk (256 / C row lanes per channel), joined in lane order through LDS;
+// bn_finish_kernel adds the chunks)
 
 // mode 0: partial[chunk][0][c] = sum x, [1][c] = sum x^2
 // mode 1: g = dy * (y > 0): [0][c] = sum g, [1][c] = sum g * xhat,  xhat = (x - mean) * rstd
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dy, const float* __restrict__ stats,
                                                          float* __restrict__ partial, int64_t R, int C, int mode) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[2][256];
+  int cl = 256;  // channels per workgroup: the largest power of two <= min(C, 256) -- the rest of the threads are row lanes
+  while (cl > C) cl >>= 1;
+  const int lanes = 256 / cl;
+  const int lc = threadIdx.x % cl, rl = threadIdx.x / cl;
+  const int c = blockIdx.x * cl + lc;
   const int64_t per = bn_rows_per_chunk(R);
   const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(R, r0 + per);
   float s0 = 0.f, s1 = 0.f;
-  if (mode == 0) {
-    for (int64_t r = r0; r < r1; ++r) {
-      const float v = x[r * C + c];
-      s0 += v;
-      s1 += v * v;
+  if (c < C) {
+    if (mode == 0) {
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        const float v = x[r * C + c];
+        s0 += v;
+        s1 += v * v;
+      }
+    } else {
+      const float mean = stats[c], rstd = stats[C + c];
+      for (int64_t r = r0 + rl; r < r1; r += lanes) {
+        const float g = y[r * C + c] > 0.f ? dy[r * C + c] : 0.f;
+        s0 += g;
+        s1 += g * ((x[r * C + c] - mean) * rstd);
+      }
     }
-  } else {
-    const float mean = stats[c], rstd = stats[C + c];
-    for (int64_t r = r0; r < r1; ++r) {
-      const float g = y[r * C + c] > 0.f ? dy[r * C + c] : 0.f;
-      s0 += g;
-      s1 += g * ((x[r * C + c] - mean) * rstd);
-    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int l = 1; l < lanes; ++l) {
+    s0 += red[0][l * cl + lc];
+    s1 += red[1][l * cl + lc];
   }
   partial[((int64_t)blockIdx.y * 2) * C + c] = s0;
   partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+}
+
+inline unsigned bn_channel_blocks(int C) {
+  int cl = 256;
+  while (cl > C) cl >>= 1;
+  return (unsigned)((C + cl - 1) / cl);
 }
 
 // sums the chunks in a fixed order (four interleaved runs per channel, combined 0..3).  mode 0: stats = (mean, rstd) with
@@ -348,7 +370,7 @@ extern "C" int srn_bn_relu_fwd(const float* x, const float* gamma, const float* 
   const int chunks = srn_bn_chunks(rows);
   SRN_CHECK_ARG(chunks < 65536, "bn_relu_fwd: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned cb = (unsigned)((C + 255) / 256);
+  const unsigned cb = bn_channel_blocks(C);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, chunks), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0);
   hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, (const float*)partial, stats,
@@ -368,7 +390,7 @@ extern "C" int srn_bn_relu_bwd(const float* x, const float* y, const float* dy, 
   const int chunks = srn_bn_chunks(rows);
   SRN_CHECK_ARG(chunks < 65536, "bn_relu_bwd: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned cb = (unsigned)((C + 255) / 256);
+  const unsigned cb = bn_channel_blocks(C);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(cb, chunks), dim3(256), 0, st, x, y, dy, stats, partial, rows, C, 1);
   hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, (const float*)partial, sums,
                      (float*)nullptr, (float*)nullptr, chunks, rows, C, 0.f, 0.f, 1);
