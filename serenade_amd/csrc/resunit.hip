@@ -13,7 +13,8 @@
 //      zero-pads ITS input), and runs conv2 the same way;
 //   4. epilogue: + bias + x (exact fp32 from global) [+ res2] [/ post_div], BMI - (k-1) output rows.
 // conv1 is over-computed by (k-1) / BMI (8 % at k = 11, C = 64); HBM traffic is one read of x (+ its L2-hit re-read as
-// the residual) and one write of y.  4 waves per workgroup (wave tile 32 MT x C), two workgroups per CU.
+// the residual) and one write of y.  Two workgroups per CU; 4 waves each (wave tile 32 MT x C) in the split-bf16 mode,
+// 8 waves (32 x 32 per wave) in exact fp32, see RCfg.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -39,11 +40,16 @@ __device__ __forceinline__ void split_pair_r(const float a, const float b, unsig
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2r));
 }
 
-template <int C_, int PREC_>
+template <int C_, int PREC_, int NW_ = 4>
 struct RCfg {
-  static constexpr int C = C_, PREC = PREC_;
+  static constexpr int C = C_, PREC = PREC_, NW = NW_, NTH = 64 * NW_;
   static constexpr int CH = C / 32, NT = C / 32, MT = C == 32 ? 2 : 1;
-  static constexpr int BMI = 128 * MT;                 // intermediate rows per tile: 4 waves x 32 MT
+  // NW = 4: a wave owns 32 MT rows x all C columns.  NW = 8 (exact fp32): 32 rows x 32 columns per wave -- 8 row groups at
+  // C = 32, 4 row groups x 2 column groups at C = 64 -- so the same image feeds twice the waves (4 per SIMD at two
+  // workgroups per CU): the fp32 loop is latency-bound at 2 waves per SIMD (MFMA pipe 0.58-0.67 busy), not LDS-bound
+  static constexpr int MTW = NW == 8 ? 1 : MT, NTW = NW == 8 ? 1 : NT;
+  static_assert(NW == 4 || (NW == 8 && PREC == 0), "eight waves: exact fp32 only");
+  static constexpr int BMI = 128 * MT;                 // intermediate rows per tile
   static constexpr int ROWB = PREC ? 64 : 144;         // bytes of one row of one 32-channel chunk (plane)
   static constexpr int PL = PREC ? 2 : 1;              // planes: (hi, lo) or fp32
   static constexpr int A_ROWS = BMI + RU_HALO_MAX + 2;
@@ -54,15 +60,15 @@ struct RCfg {
   static constexpr int STAGE = G * UNIT;
   static constexpr int SMEM = A_BYTES + 2 * STAGE;
   static constexpr int F4R = C / 4;                    // float4 pieces per input row
-  static constexpr int A_LD = (A_ROWS * F4R + 255) / 256;
-  static constexpr int W_LD = G * C * 8 / 256;         // 16-B pieces per thread per stage
-  static_assert(G * C * 8 % 256 == 0, "stage pieces must divide over the workgroup");
+  static constexpr int A_LD = (A_ROWS * F4R + NTH - 1) / NTH;
+  static constexpr int W_LD = G * C * 8 / NTH;         // 16-B pieces per thread per stage
+  static_assert(G * C * 8 % NTH == 0, "stage pieces must divide over the workgroup");
 };
 
 template <class R>
-__global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams p, const int tiles_per_z,
-                                                         const int n_tiles) {
-  constexpr int C = R::C, CH = R::CH, NT = R::NT, MT = R::MT, BMI = R::BMI, G = R::G;
+__global__ __launch_bounds__(R::NTH, R::NW / 2) void resunit_kernel(const SrnResUnitParams p, const int tiles_per_z,
+                                                            const int n_tiles) {
+  constexpr int C = R::C, CH = R::CH, NT = R::NTW, MT = R::MTW, BMI = R::BMI, G = R::G, NTH = R::NTH;
   constexpr bool BF = R::PREC != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
   unsigned char* sA = smem_r;
@@ -85,16 +91,17 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
   //      piece (tid & 7) of weight row n = (tid >> 3) + 32 (i & 1) [C = 64] of unit i >> 1 [C = 64] / i [C = 32]:
   //      everything but the unit is fixed per thread, so a stage costs one address and immediates
   constexpr int W_LD = R::W_LD;
+  constexpr int PU = C * 8;  // 16-B pieces of one unit: piece q = tid + NTH i is piece q % 8 of row (q % PU) / 8 of unit q / PU
   const int w_piece = tid & 7;
-  const int w_n = tid >> 3;
   uint4 wr[W_LD];
   auto w_load = [&](const int j) {
     const int conv = j >= S;
     const int u0 = (conv ? j - S : j) * G;
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-      const int g = C == 64 ? i >> 1 : i;
-      const int n = w_n + (C == 64 ? 32 * (i & 1) : 0);
+      const int q = tid + NTH * i;
+      const int g = q / PU;
+      const int n = (q % PU) >> 3;
       const int u = min(u0 + g, U - 1);  // a partial last stage re-reads the last unit; it is never multiplied
       const uint4* src;
       if constexpr (BF)
@@ -104,14 +111,15 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
       wr[i] = *src;
     }
   };
-  const int w_dst0 = BF ? (w_piece >> 2) * (C * 64) + bf_off(w_n, (w_piece & 3) * 8) : w_n * 144 + w_piece * 16;
   auto w_store = [&](const int buf) {
-    unsigned char* base = sW + buf * R::STAGE + w_dst0;
+    unsigned char* base = sW + buf * R::STAGE;
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-      const int g = C == 64 ? i >> 1 : i;
-      const int nhi = C == 64 ? (i & 1) : 0;  // rows n + 32: same swizzle key, 32 rows further
-      const int off = BF ? g * 2 * (C * 64) + nhi * 32 * 64 : (g * C + nhi * 32) * 144;
+      const int q = tid + NTH * i;
+      const int g = q / PU;
+      const int n = (q % PU) >> 3;
+      const int off = BF ? g * 2 * (C * 64) + (w_piece >> 2) * (C * 64) + bf_off(n, (w_piece & 3) * 8)
+                         : (g * C + n) * 144 + w_piece * 16;
       // through an opaque asm: the optimizer turns a pure global -> register -> LDS copy of the set into memcpys
       // of a stack object (scratch)
       uint4 v = wr[i];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
   // ---- receptive-field image: piece q = tid + 256 j is float4 (tid % F4R) of image row tid / F4R + RSTEP j.  Rows are
   //      loaded from a clamped address and zeroed at staging time by a validity bit (one pointer + one mask instead
   //      of a pointer per piece)
-  constexpr int A_LD = R::A_LD, F4R = R::F4R, RSTEP = 256 / F4R;
+  constexpr int A_LD = R::A_LD, F4R = R::F4R, RSTEP = NTH / F4R;
   const int a_f4 = tid % F4R;
   const int a_r0 = tid / F4R;
   float4 pa[A_LD];
@@ -164,7 +172,9 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
     }
   };
 
-  const int wm0 = wave * 32 * MT;
+  // NW = 4: wave = row group, all columns.  NW = 8: 32 x 32 per wave; at C = 64 waves 4-7 take the second 32 columns
+  const int wm0 = (R::NW == 8 && C == 64 ? (wave & 3) : wave) * 32 * MT;
+  const int ng0 = R::NW == 8 && C == 64 ? (wave >> 2) : 0;  // first 32-column block of this wave
   f32x16 acc[MT][NT];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
           }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            const int o = bf_off(n * 32 + li, kk * 16 + lh * 8);
+            const int o = bf_off((ng0 + n) * 32 + li, kk * 16 + lh * 8);
             bh[n] = *reinterpret_cast<const bf16x8*>(wb + (g * 2) * (C * 64) + o);
             bl[n] = *reinterpret_cast<const bf16x8*>(wb + (g * 2 + 1) * (C * 64) + o);
           }
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
         }
       } else {
         const float* a = reinterpret_cast<const float*>(sA + c * R::A_PLANE) + (wm0 + li + tap * step) * 36 + 4 * lh;
-        const float* b = reinterpret_cast<const float*>(wb + g * C * 144) + li * 36 + 4 * lh;
+        const float* b = reinterpret_cast<const float*>(wb + g * C * 144) + (ng0 * 32 + li) * 36 + 4 * lh;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           float4 af[MT], bf[NT];
@@ -296,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const float bias = p.b1[n * 32 + li];
+        const int na = ng0 + n;  // 32-column block of the intermediate = channel chunk of conv2's image
+        const float bias = p.b1[na * 32 + li];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           // rows mrow0 .. mrow0 + 3 of column li: one swizzle key per row quad ((mrow >> 2) & 3 = (2 gq + lh) & 3)
@@ -312,10 +323,10 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
             if constexpr (BF) {
               const __bf16 h = (__bf16)v;
               const __bf16 l = (__bf16)(v - (float)h);
-              *reinterpret_cast<__bf16*>(sA + (n * 2) * R::A_PLANE + off0 + i * 64) = h;
-              *reinterpret_cast<__bf16*>(sA + (n * 2 + 1) * R::A_PLANE + off0 + i * 64) = l;
+              *reinterpret_cast<__bf16*>(sA + (na * 2) * R::A_PLANE + off0 + i * 64) = h;
+              *reinterpret_cast<__bf16*>(sA + (na * 2 + 1) * R::A_PLANE + off0 + i * 64) = l;
             } else {
-              *reinterpret_cast<float*>(sA + n * R::A_PLANE + off0 + i * 144) = v;
+              *reinterpret_cast<float*>(sA + na * R::A_PLANE + off0 + i * 144) = v;
             }
           }
         }
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void resunit_kernel(const SrnResUnitParams 
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int col = n * 32 + li;
+        const int col = (ng0 + n) * 32 + li;
         const float bias = p.b2[col];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -375,7 +386,7 @@ int launch_resunit(const SrnResUnitParams& p, hipStream_t stream) {
   const int64_t n_tiles = (int64_t)p.n_batch * tiles_per_z;
   SRN_CHECK_ARG(n_tiles > 0 && n_tiles < (1ll << 31), "resunit: bad tile count %lld", (long long)n_tiles);
   const int grid = (int)(n_tiles < 512 ? n_tiles : 512);  // persistent: two workgroups per CU
-  hipLaunchKernelGGL((resunit_kernel<R>), dim3(grid), dim3(256), R::SMEM, stream, p, tiles_per_z, (int)n_tiles);
+  hipLaunchKernelGGL((resunit_kernel<R>), dim3(grid), dim3(R::NTH), R::SMEM, stream, p, tiles_per_z, (int)n_tiles);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -399,5 +410,7 @@ extern "C" int srn_hifigan_resunit(const SrnResUnitParams* pp, void* stream_) {
     SRN_CHECK_ARG(p.w1_hi && p.w2_hi, "resunit: split-bf16 mode needs the weight planes w1_hi / w2_hi");
     return p.C == 32 ? launch_resunit<RCfg<32, 1>>(p, stream) : launch_resunit<RCfg<64, 1>>(p, stream);
   }
-  return p.C == 32 ? launch_resunit<RCfg<32, 0>>(p, stream) : launch_resunit<RCfg<64, 0>>(p, stream);
+  // exact fp32: eight waves per workgroup (A/B on the B = 8 x T = 1024 vocoder, 4 -> 8 waves: k 3 units 0.62 -> 0.51 ms,
+  // k 7 1.17 -> 1.05, k 11 1.74 -> 1.61 at C = 64; all 18 units 16.7 -> 14.9 ms)
+  return p.C == 32 ? launch_resunit<RCfg<32, 0, 8>>(p, stream) : launch_resunit<RCfg<64, 0, 8>>(p, stream);
 }
