@@ -38,7 +38,7 @@ def make_case(seed):
     w = rnd(N, C, k, seed=seed * 7 + 1) * (1.0 / np.sqrt(C * k))
     kw = dict(in0=rnd(B, T, C, seed=seed * 7 + 2), w=ops.pack_conv_weight(w), out=torch.zeros(B, To, N), n_batch=B,
               T_in=T, T_out=To, C_in=C, N=N, in0_bs=T * C, ld_in0=C, ldw=k * C, out_bs=To * N, ld_out=N, taps=taps,
-              in_stride=stride, tile=pick([0, 0, 1, 2, 3, 4, 5]))
+              in_stride=stride, tile=pick([0, 0, 1, 2, 3, 4, 5, 7, 9]))
     if pick([0, 1]):
         kw["bias"] = rnd(N, seed=seed * 7 + 3)
     if C % 32 == 0 and C >= 64 and pick([0, 0, 1]):  # concat input: the K range comes from two tensors

@@ -124,7 +124,7 @@ def rnd(*s, seed=0):
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(s).astype(np.float32))
 
 
-ALL_TILES = (0, 1, 2, 3, 4, 5)
+ALL_TILES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)  # 6-9: the single-LDS-stage forms
 
 
 def test_library_exports_and_error_path(dev):
