@@ -683,8 +683,10 @@ class Estimator:
         the transposes that read the packed buffers."""
         P, dev = self.params, self.device
         z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self._pk, self._wd, self._pack_names, self._relay_ops = {}, {}, [], []
+        if "down_blocks.0.0.block1.block.0.weight" not in P:
+            return  # not a decoder's state_dict (GradSync's unit tests hand a bare ParamStore): nothing to re-lay
         cin0 = P["down_blocks.0.0.block1.block.0.weight"].shape[1]
-        self._pk, self._wd, self._pack_names = {}, {}, []
         first, second = [], []
         for name, w in P.items():
             if not name.endswith(".weight") or w.dim() not in (2, 3):
