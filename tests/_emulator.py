@@ -503,6 +503,7 @@ def emul_tn_gemm(kw):
     a, oa = _flat(g("a"))
     b, ob = _flat(g("b"))
     out, oo = _flat(g("out"))
+    oa, ob, oo = oa + a.storage_offset(), ob + b.storage_offset(), oo + out.storage_offset()  # as_strided counts from the storage
     M, N, T_a, T_b, stride = g("M"), g("N"), g("T_a"), g("T_b"), g("stride")
     len_b, colsum = g("len_b"), g("colsum")
     if colsum is not None:
@@ -543,10 +544,10 @@ def emul_multi_copy(self_, stream=None):
 def emul_transpose_multi(self_, stream=None):
     """executable spec of srn_transpose_multi: entry e does dst[b][c][r] = src[b][r][c]"""
     for src, dst, B, R, Cc, sbs, lds, dbs, ldd in self_.entries:
-        sf, df = _v(src), _v(dst)
-        rr, cc = torch.arange(R).unsqueeze(1), torch.arange(Cc).unsqueeze(0)
-        for b in range(B):
-            df[b * dbs + cc * ldd + rr] = sf[b * sbs + rr * lds + cc]
+        (sf, so), (df, do) = _flat(src), _flat(dst)
+        # (as_strided offsets count from the storage, and parameters are views into the flat buffer)
+        torch.as_strided(df, (B, Cc, R), (dbs, ldd, 1), do + df.storage_offset()).copy_(
+            torch.as_strided(sf, (B, R, Cc), (sbs, lds, 1), so + sf.storage_offset()).transpose(1, 2))
 
 
 class installed:
