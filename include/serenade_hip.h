@@ -346,6 +346,15 @@ typedef struct SrnCopyList {
 } SrnCopyList;
 int srn_multi_copy(const SrnCopyList* list, float* dst, void* stream);
 int srn_sumsq_blocks(int64_t n);
+/* torch.nn.utils.weight_norm of the content encoder's convs (serenade/models/serenade.py `Conv1dResnet`; w = g v / ||v||
+ * per output channel) fused with the re-layout the conv kernels want: forward writes the packed k-major rows
+ * w[n][j * C + c] = g[n] v[n][c][j] / ||v[n]||, optionally W^T for the input gradient wd[c][j * N + n], and 1 / ||v[n]||;
+ * backward takes the packed dW and returns dv (N, C, k) and dg (N,).  One workgroup per output channel, fixed summation
+ * order.  (Eleven convs x ~14 torch launches per step otherwise.) */
+int srn_weight_norm_fwd(const float* v, const float* g, float* w_packed, float* wd, float* inv_norm, int N, int C, int k,
+                        void* stream);
+int srn_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, const float* inv_norm, float* dv,
+                        float* dg, int N, int C, int k, void* stream);
 
 /*
  * Analysis front-end between HiFi-GAN and SiFiGAN -- SURVEY 8 row f1, serenade/bin/ssc_postprocessing.py:142-222.

@@ -117,6 +117,8 @@ _SIGS = {
     "srn_copy_channels": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "srn_transpose_ct": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int, c_int64, c_int, _P]),
     "srn_transpose_multi": (c_int, [POINTER(SrnTransposeList), _P]),
+    "srn_weight_norm_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "srn_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "srn_renorm": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "srn_out_conv_tanh": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "srn_pd_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),

@@ -487,12 +487,85 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const SrnCopyList list,
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) d[i] = src[i];
 }
 
+// ---- weight norm + re-layout, one workgroup per output channel (see serenade_hip.h)
+__device__ inline float block_sum_256(float x, float* red) {  // fixed order: lanes, then the four waves 0..3
+  x = wave_sum(x);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  const float r = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ w, float* __restrict__ wd,
+                                                              float* __restrict__ inv_norm, int N, int C, int k) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, E = C * k;
+  const float* vn = v + (int64_t)n * E;
+  float ss = 0.f;
+  for (int e = threadIdx.x; e < E; e += 256) ss += vn[e] * vn[e];
+  ss = block_sum_256(ss, red);
+  const float inv = 1.0f / sqrtf(ss);
+  const float sc = g[n] * inv;
+  if (threadIdx.x == 0) inv_norm[n] = inv;
+  float* wn = w + (int64_t)n * E;
+  for (int e = threadIdx.x; e < E; e += 256) {  // e walks the PACKED row: (j, c)
+    const int j = e / C, c = e - j * C;
+    const float x = sc * vn[c * k + j];
+    wn[e] = x;
+    if (wd) wd[(int64_t)c * k * N + (int64_t)j * N + n] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                              const float* __restrict__ g,
+                                                              const float* __restrict__ inv_norm, float* __restrict__ dv,
+                                                              float* __restrict__ dg, int N, int C, int k) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, E = C * k;
+  const float* vn = v + (int64_t)n * E;
+  const float* dn = dw + (int64_t)n * E;
+  float dot = 0.f;
+  for (int e = threadIdx.x; e < E; e += 256) {  // e walks v's row: (c, j)
+    const int c = e / k, j = e - c * k;
+    dot += dn[j * C + c] * vn[e];
+  }
+  dot = block_sum_256(dot, red);
+  const float inv = inv_norm[n], gn = g[n];
+  if (threadIdx.x == 0) dg[n] = dot * inv;
+  const float a = gn * inv, b = dot * inv * inv;
+  float* o = dv + (int64_t)n * E;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const int c = e / k, j = e - c * k;
+    o[e] = a * (dn[j * C + c] - vn[e] * b);
+  }
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 16384) {
   int64_t b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 }  // namespace
+
+extern "C" int srn_weight_norm_fwd(const float* v, const float* g, float* w_packed, float* wd, float* inv_norm, int N,
+                                   int C, int k, void* stream) {
+  SRN_CHECK_ARG(v && g && w_packed && inv_norm && N > 0 && C > 0 && k > 0, "weight_norm_fwd: bad args");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, v, g, w_packed, wd,
+                     inv_norm, N, C, k);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_weight_norm_bwd(const float* dw_packed, const float* v, const float* g, const float* inv_norm,
+                                   float* dv, float* dg, int N, int C, int k, void* stream) {
+  SRN_CHECK_ARG(dw_packed && v && g && inv_norm && dv && dg && N > 0 && C > 0 && k > 0, "weight_norm_bwd: bad args");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, dw_packed, v, g,
+                     inv_norm, dv, dg, N, C, k);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int srn_rowln_fwd(const float* x, const float* m, int64_t m_bs, const float* a, int64_t a_bs, float* y, int B,
                              int T, int C, float eps, void* stream) {

@@ -208,6 +208,23 @@ def emul_call(name, a):
         tt, cc = torch.arange(T).unsqueeze(1), torch.arange(C).unsqueeze(0)
         for b in range(B):
             df[b * dbs + tt * ldd + dc0 + cc] = sf[b * sbs + tt * lds + sc0 + cc]
+    elif name == "srn_weight_norm_fwd":
+        v, g, w, wd, inv, N, C, k = a
+        vv = _v(v, N * C * k).reshape(N, C, k).double()
+        nrm = vv.reshape(N, -1).norm(dim=1)
+        wp = (vv * (_v(g, N).double() / nrm).reshape(N, 1, 1)).permute(0, 2, 1)  # (N, k, C)
+        _v(w, N * k * C).reshape(N, k, C)[:] = wp.float()
+        _v(inv, N)[:] = (1.0 / nrm).float()
+        if wd is not None:
+            _v(wd, C * k * N).reshape(C, k, N)[:] = wp.permute(2, 1, 0).float()
+    elif name == "srn_weight_norm_bwd":
+        dw, v, g, inv, dv, dg, N, C, k = a
+        vv = _v(v, N * C * k).reshape(N, C, k).double()
+        dd = _v(dw, N * k * C).reshape(N, k, C).double().permute(0, 2, 1)  # (N, C, k)
+        iv, gg = _v(inv, N).double(), _v(g, N).double()
+        dot = (dd * vv).reshape(N, -1).sum(1)
+        _v(dg, N)[:] = (dot * iv).float()
+        _v(dv, N * C * k).reshape(N, C, k)[:] = ((gg * iv).reshape(N, 1, 1) * (dd - vv * (dot * iv * iv).reshape(N, 1, 1))).float()
     elif name == "srn_transpose_ct":
         src, dst, B, R, Cc, sbs, lds, dbs, ldd = a
         sf, df = _v(src), _v(dst)

@@ -451,3 +451,22 @@ def test_tn_gemm_against_fp64(dev, case):
         got = out.cpu().double()[:, :, 2 * H * hd:].view(B, L, H, hd)
         assert (got - ref).abs().max() < 2e-5 * ref.abs().max()
         assert not out[:, :, :2 * H * hd].any()  # nothing outside the head slices was touched
+
+
+# ---- fused weight norm + re-layout (the content encoder's convs) against torch autograd of the same expression
+@pytest.mark.parametrize("shape", [(96, 64, 3), (80, 768, 7), (512, 512, 1)])
+def test_weight_norm_pack_against_torch(dev, shape):
+    n, c, k = shape
+    g0 = torch.Generator().manual_seed(n + k)
+    v = torch.randn(n, c, k, generator=g0).to(dev).requires_grad_(True)
+    g = (torch.rand(n, 1, 1, generator=g0) + 0.5).to(dev).requires_grad_(True)
+    co = torch.randn(n, k * c, generator=g0).to(dev)
+    w, wd = training._WeightNormPack.apply(v, g)
+    (w * co).sum().backward()
+    v2, g2 = v.detach().clone().double().requires_grad_(True), g.detach().clone().double().requires_grad_(True)
+    ref = (v2 * (g2 / v2.reshape(n, -1).norm(dim=1).reshape(n, 1, 1))).permute(0, 2, 1).reshape(n, k * c)
+    (ref * co.double()).sum().backward()
+    assert (w.double() - ref).abs().max() < 1e-6 * ref.abs().max()
+    assert torch.equal(wd.view(c, k, n), w.view(n, k, c).permute(2, 1, 0))  # W^T of the same numbers
+    assert (v.grad.double() - v2.grad).abs().max() < 2e-5 * v2.grad.abs().max()
+    assert (g.grad.double() - g2.grad).abs().max() < 2e-5 * g2.grad.abs().max()
