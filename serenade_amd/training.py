@@ -43,6 +43,9 @@ def _call(name, *args):
     ops.CallOp(name, args)()
 
 
+NORM_BWD_ROWS = 8  # rows per chunk of partial sums in the LayerNorm / GroupNorm backward kernels (srn_rowln_chunks, srn_gn_chunks)
+
+
 def _rup(n, m):
     return (n + m - 1) // m * m
 
@@ -301,7 +304,7 @@ class _GNMish(torch.autograd.Function):
         G = ctx.groups
         B, T, C = h.shape
         dy = dy.contiguous()
-        nch = (T + 31) // 32
+        nch = (T + NORM_BWD_ROWS - 1) // NORM_BWD_ROWS
         part = torch.empty(B, nch, 2, C, device=h.device, dtype=torch.float32)
         _call("srn_gn_mish_bwd_partial", h, dy, mean, rstd, gamma, beta, lens, part, B, T, C, G)
         col = torch.empty(B, 2, C, device=h.device, dtype=torch.float32)  # sum_t dg, sum_t dg * xhat
@@ -338,7 +341,7 @@ class _RowLN(torch.autograd.Function):
         x, m = ctx.saved_tensors
         B, T, C = x.shape
         dy = dy.contiguous()
-        nch = (T + 31) // 32
+        nch = (T + NORM_BWD_ROWS - 1) // NORM_BWD_ROWS
         part = torch.empty(B, nch, 2, C, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         _call("srn_rowln_bwd", x, dy, m, C if ctx.per_b else 0, dx, part, B, T, C, ctx.eps)

@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from serenade_amd import _lib, models, ops, vocoder
+from serenade_amd import _lib, models, ops, training, vocoder
 
 
 def _flat(x):
@@ -315,11 +315,12 @@ def emul_call(name, a):
             xh = F.layer_norm(xv, (C,), None, None, eps)
             (xh * mv.unsqueeze(1)).backward(dv)
         _v(dx, B * T * C).reshape(B, T, C)[:] = xv.grad
-        nch = (T + 31) // 32
+        R = training.NORM_BWD_ROWS
+        nch = (T + R - 1) // R
         pv = _v(part, B * nch * 2 * C).reshape(B, nch, 2, C)
         xh = xh.detach()
         for c in range(nch):
-            sl = slice(c * 32, min(T, (c + 1) * 32))
+            sl = slice(c * R, min(T, (c + 1) * R))
             pv[:, c, 0] = (dv[:, sl] * xh[:, sl]).sum(1)
             pv[:, c, 1] = dv[:, sl].sum(1)
     elif name in ("srn_gn_mish_bwd_partial", "srn_gn_mish_bwd_apply"):
@@ -337,10 +338,11 @@ def emul_call(name, a):
         valid = (torch.arange(T)[None, :, None] < (_v(lens, B).reshape(B, 1, 1) if lens is not None else T)).float()
         dg = dv * gpre.grad * valid
         if name.endswith("partial"):
-            nch = (T + 31) // 32
+            R = training.NORM_BWD_ROWS
+            nch = (T + R - 1) // R
             pv = _v(out, B * nch * 2 * C).reshape(B, nch, 2, C)
             for c in range(nch):
-                sl = slice(c * 32, min(T, (c + 1) * 32))
+                sl = slice(c * R, min(T, (c + 1) * R))
                 pv[:, c, 0] = dg[:, sl].sum(1)
                 pv[:, c, 1] = (dg[:, sl] * xh[:, sl]).sum(1)
         else:

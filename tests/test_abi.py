@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from serenade_amd import _lib, build
+from serenade_amd import _lib, build, training
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "serenade_hip.h")
@@ -68,7 +68,8 @@ def test_partial_sum_chunk_sizes_match_the_host_code():
     from serenade_amd import _lib
     h = _lib.lib()
     for T in (1, 31, 32, 33, 1000, 4352):
-        assert h.srn_rowln_chunks(T) == (T + 31) // 32 == h.srn_gn_chunks(T)
+        R = training.NORM_BWD_ROWS  # the host allocates the partial sums by this constant
+        assert h.srn_rowln_chunks(T) == (T + R - 1) // R == h.srn_gn_chunks(T)
     assert 1 <= h.srn_sumsq_blocks(10) <= h.srn_sumsq_blocks(84_287_728) <= 1024
     for R in (1, 32, 33, 4096):
         assert h.srn_colsum_chunks(R) == (R + 31) // 32
