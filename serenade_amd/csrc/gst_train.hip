@@ -19,56 +19,63 @@ namespace {
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
 // rows per partial-sum chunk: at most ~256 chunks, so the finishing kernel's ordered sum stays short
 __host__ __device__ inline int64_t bn_rows_per_chunk(int64_t R) { return R <= 256 * 16 ? 16 : (R + 255) / 256; }
-// (bn_partial_kernel: a workgroup takes up to 256 channels of one chunk; with fewer channels -- the GST's 32 .. 128 --
-// the spare threads take further rows of the chunk (256 / C row lanes per channel), joined in lane order through LDS;
-// bn_finish_kernel adds the chunks)
+// (bn_partial_kernel: a thread owns FOUR channels (16-B loads) of up to 1024 per workgroup; with fewer channels -- the GST's
+// 32 .. 128 -- the spare threads take further rows of the chunk (256 / (C / 4) row lanes), joined in lane order through
+// LDS; bn_finish_kernel adds the chunks)
 
 // mode 0: partial[chunk][0][c] = sum x, [1][c] = sum x^2
 // mode 1: g = dy * (y > 0): [0][c] = sum g, [1][c] = sum g * xhat,  xhat = (x - mean) * rstd
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dy, const float* __restrict__ stats,
                                                          float* __restrict__ partial, int64_t R, int C, int mode) {
-  __shared__ float red[2][256];
-  int cl = 256;  // channels per workgroup: the largest power of two <= min(C, 256) -- the rest of the threads are row lanes
-  while (cl > C) cl >>= 1;
-  const int lanes = 256 / cl;
-  const int lc = threadIdx.x % cl, rl = threadIdx.x / cl;
-  const int c = blockIdx.x * cl + lc;
+  __shared__ float4 red[2][256];
+  const int c4n = C / 4;                      // C % 4 == 0 (checked by the callers)
+  const int cw = c4n < 256 ? c4n : 256;       // channel quads per workgroup
+  const int lanes = 256 / cw;                 // row lanes per quad (>= 1); threads past lanes * cw idle
+  const int lc = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int c = (blockIdx.x * cw + lc) * 4;
+  const bool live = rl < lanes && c < C;
   const int64_t per = bn_rows_per_chunk(R);
   const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(R, r0 + per);
-  float s0 = 0.f, s1 = 0.f;
-  if (c < C) {
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (live) {
     if (mode == 0) {
       for (int64_t r = r0 + rl; r < r1; r += lanes) {
-        const float v = x[r * C + c];
-        s0 += v;
-        s1 += v * v;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+        s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
+        s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
       }
     } else {
-      const float mean = stats[c], rstd = stats[C + c];
+      const float4 mean = *reinterpret_cast<const float4*>(stats + c);
+      const float4 rstd = *reinterpret_cast<const float4*>(stats + C + c);
       for (int64_t r = r0 + rl; r < r1; r += lanes) {
-        const float g = y[r * C + c] > 0.f ? dy[r * C + c] : 0.f;
-        s0 += g;
-        s1 += g * ((x[r * C + c] - mean) * rstd);
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + r * C + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+        const float g0 = yv.x > 0.f ? dv.x : 0.f, g1 = yv.y > 0.f ? dv.y : 0.f;
+        const float g2 = yv.z > 0.f ? dv.z : 0.f, g3 = yv.w > 0.f ? dv.w : 0.f;
+        s0.x += g0, s0.y += g1, s0.z += g2, s0.w += g3;
+        s1.x += g0 * ((xv.x - mean.x) * rstd.x), s1.y += g1 * ((xv.y - mean.y) * rstd.y);
+        s1.z += g2 * ((xv.z - mean.z) * rstd.z), s1.w += g3 * ((xv.w - mean.w) * rstd.w);
       }
     }
   }
   red[0][threadIdx.x] = s0;
   red[1][threadIdx.x] = s1;
   __syncthreads();
-  if (rl != 0 || c >= C) return;
+  if (rl != 0 || !live) return;
   for (int l = 1; l < lanes; ++l) {
-    s0 += red[0][l * cl + lc];
-    s1 += red[1][l * cl + lc];
+    const float4 a = red[0][l * cw + lc], b = red[1][l * cw + lc];
+    s0.x += a.x, s0.y += a.y, s0.z += a.z, s0.w += a.w;
+    s1.x += b.x, s1.y += b.y, s1.z += b.z, s1.w += b.w;
   }
-  partial[((int64_t)blockIdx.y * 2) * C + c] = s0;
-  partial[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+  *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * 2) * C + c) = s0;
+  *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * 2 + 1) * C + c) = s1;
 }
 
 inline unsigned bn_channel_blocks(int C) {
-  int cl = 256;
-  while (cl > C) cl >>= 1;
-  return (unsigned)((C + cl - 1) / cl);
+  const int c4n = C / 4;
+  return (unsigned)(c4n <= 256 ? 1 : (c4n + 255) / 256);
 }
 
 // sums the chunks in a fixed order (four interleaved runs per channel, combined 0..3).  mode 0: stats = (mean, rstd) with
