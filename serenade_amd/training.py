@@ -345,12 +345,13 @@ class _RowLN(torch.autograd.Function):
         part = torch.empty(B, nch, 2, C, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         _call("srn_rowln_bwd", x, dy, m, C if ctx.per_b else 0, dx, part, B, T, C, ctx.eps)
-        col = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
-        _call("srn_chunk_colsum", part, None, col, None, B, nch, C, 1)
         if ctx.per_b:
+            col = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
+            _call("srn_chunk_colsum", part, None, col, None, B, nch, C, 1)
             return dx, col[:, 0].contiguous(), col[:, 1].contiguous(), None
-        dcol = col.sum(0)
-        return dx, dcol[0], dcol[1], None
+        col = torch.empty(2, C, device=x.device, dtype=torch.float32)  # shared weights: one sum over all items' chunks
+        _call("srn_chunk_colsum", part, None, col, None, 1, B * nch, C, 1)
+        return dx, col[0], col[1], None
 
 
 def row_ln(x, m, a, eps=1e-5):
