@@ -80,6 +80,7 @@ class _Conv(torch.autograd.Function):
         if want_gn:
             part = torch.empty(B, (T_out + 31) // 32, N // 32, 2, device=x.device, dtype=torch.float32)
         assert lens is None or stride == 1
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the non-differentiable partial sums
         _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part, len_in=lens)
         ctx.save_for_backward(x, w)
         ctx.taps, ctx.stride, ctx.has_bias, ctx.lens, ctx.wd = tuple(taps), stride, bias is not None, lens, wd
@@ -90,6 +91,8 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_):
+        if dy is None:
+            return (None,) * 9
         x, w = ctx.saved_tensors
         taps, stride, lens = ctx.taps, ctx.stride, ctx.lens
         B, T, C = x.shape
@@ -254,10 +257,13 @@ class _WeightNormPack(torch.autograd.Function):
         _call("srn_weight_norm_fwd", v, g, w, wd, inv, n, c, k)
         ctx.save_for_backward(v, g, inv)
         ctx.mark_non_differentiable(wd)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" of wd
         return w, wd
 
     @staticmethod
     def backward(ctx, dw, _):
+        if dw is None:
+            return None, None
         v, g, inv = ctx.saved_tensors
         n, c, k = v.shape
         dv = torch.empty_like(v)
@@ -947,12 +953,18 @@ def cfm_loss(estimator, x1, mask, mu, spks, mask_l=None, draws=None, sigma_min=1
 # =====================================================================================================================
 #  the whole model: Serenade.forward (serenade.py:90-166) for training
 # =====================================================================================================================
+_REFLECT_IDX = {}
+
+
 def _reflect_pad_rows(x, p):
     """nn.ReflectionPad1d(p) along time of a channels-last (B, T, C) tensor (a gather: autograd scatters back)"""
     T = x.shape[1]
     d = x.device  # built on the device: a captured step may not copy from the host
-    idx = torch.cat([torch.arange(p, 0, -1, device=d), torch.arange(T, device=d),
-                     torch.arange(T - 2, T - 2 - p, -1, device=d)])
+    key = (T, p, str(d))
+    idx = _REFLECT_IDX.get(key)
+    if idx is None:  # once per (length, pad): three aranges + a cat per call otherwise, five calls per step
+        idx = _REFLECT_IDX[key] = torch.cat([torch.arange(p, 0, -1, device=d), torch.arange(T, device=d),
+                                             torch.arange(T - 2, T - 2 - p, -1, device=d)])
     return x.index_select(1, idx)
 
 
