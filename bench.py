@@ -294,6 +294,7 @@ def main():
                                                                   "headline (profiling runs pass one)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the "
                     "waveform gather even with one rank (single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--no-post", action="store_true", help="skip the analysis-stage (f1) secondary key")
     ap.add_argument("--graphs", type=int, default=None, help="1/0: replay the plans as hipGraphs (default: library default)")
     # the north-star's other sizes (T in {256, 1024, 4096}, 20 Euler steps); the defaults are the headline workload
     ap.add_argument("--frames", type=int, default=T_SRC, help="source mel frames per utterance")
@@ -517,6 +518,21 @@ def main():
                                                                     "captured_as_hipgraph", "peak_hbm_gib")}
         except Exception as e:  # noqa: BLE001
             out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_post:
+        # SURVEY 8 f1, a secondary key: the analysis front-end between HiFi-GAN and SiFiGAN (CheapTrick, mel-cepstrum, D4C,
+        # F0 contours, excitation; fp64, one workgroup per 5 ms frame) on the waveforms of the same batch size, and the
+        # SiFiGAN generator behind it -- tools/worldbench.py's numbers
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location(
+                "worldbench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "worldbench.py"))
+            wb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(wb)
+            serenade_amd.set_precision(modes[0])
+            out["analysis_stage"] = wb.run(B_PER_GPU, T_SRC, dev)
+        except Exception as e:  # noqa: BLE001  (never costs the headline its JSON)
+            out["analysis_stage"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_sweep:
         out["sweep"] = sweep()

@@ -33,7 +33,7 @@ SQ = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ
 
 
 def bench_cmd(mode, steps, warmup):
-    return ["python3", "bench.py", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-sweep", "--no-train", "--no-mixed",
+    return ["python3", "bench.py", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-sweep", "--no-train", "--no-mixed", "--no-post",
             "--modes", mode]
 
 

@@ -57,10 +57,10 @@ def timed(fn, iters=10, warm=2):
     return s.elapsed_time(e) / iters, out
 
 
-def main():
-    B, T = (int(v) for v in (sys.argv[1:3] + ["8", "1024"][len(sys.argv) - 1:]))
+def run(B=8, T=1024, dev=None, with_generator=True):
+    """the numbers as a dict (bench.py embeds them as the `analysis_stage` key of its line)"""
     n = T * 240
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda:0") if dev is None else dev
     sig = [singing(n, s) for s in range(B)]
     wave = torch.from_numpy(np.stack([w for w, _ in sig])).to(dev)
     lf0 = [f for _, f in sig]
@@ -94,6 +94,8 @@ def main():
     out["excitation_with_noise_draw"] = {"ms": ms}
     out["peaks"] = {"fp64_vector_tflops": 78.6, "lds_read_tb_s": 256 * 256 * 2.4e9 / 1e12,
                     "note": "one workgroup per frame (256 / 512 threads); bound by LDS round trips between barriers"}
+    if not with_generator:
+        return out
     # the generator behind it (a9), B = 1 as the reference's loop runs it, and the batch
     g = sifigan.SiFiGANGenerator(**sifigan.DEFAULT_PARAMS)
     g.load_state_dict(fill_state_dict(_shapes.as_meta(sifigan.sifigan_shapes(**sifigan.DEFAULT_PARAMS)), seed=1))
@@ -101,7 +103,12 @@ def main():
     g = g.eval().to(dev)
     ms, _ = timed(lambda: g(in_signal, c, dfs), iters=3, warm=1)
     out["sifigan_generator"] = {"ms": ms, "frames_per_s": frames / ms * 1e3, "x_realtime": B * n / FS / ms * 1e3}
-    print(json.dumps(out, indent=1))
+    return out
+
+
+def main():
+    B, T = (int(v) for v in (sys.argv[1:3] + ["8", "1024"][len(sys.argv) - 1:]))
+    print(json.dumps(run(B, T), indent=1))
 
 
 if __name__ == "__main__":
