@@ -287,6 +287,43 @@ def test_gpu_analyzer_vs_oracle_ragged_batch():
 
 
 @pytest.mark.gpu
+def test_gpu_full_size_properties():
+    """the stage at the headline's size (8 items x 10.24 s = 16 392 frames) through properties that need no oracle:
+    an item analysed alone equals itself inside the batch bit for bit; doubling the waveform shifts only c0 of the
+    mel-cepstrum (by ln 2: the envelope scales by 4) and leaves band aperiodicity, cf0 and uv untouched; everything
+    finite, aperiodicities within [-60 dB, 0], unvoiced frames at the unvoiced constant; the sine stays within its
+    amplitude"""
+    items = [song(10.24, 10 + i) for i in range(8)]
+    lf0 = [f0[::2].copy() for _, f0 in items]
+    waves = np.stack([np.clip(0.45 * x / np.abs(x).max(), -0.99, 0.99).astype(np.float32) for x, _ in items])
+    n = [waves.shape[1]] * 8
+    an = world.Analyzer(pcm16=False, noise_amp=0.0)
+    wave = _cuda(waves, torch.float32)
+    in_signal, c, dfs, feats = an(wave, n, lf0)
+    F = W.harvest_frame_count(n[0], FS)
+    assert c.shape == (8, 43, F) and 8 * F == 16392
+    for t in (in_signal, c, feats["mcep"], feats["bap"], feats["cf0"]):
+        assert torch.isfinite(t).all()
+    bap = feats["bap"].cpu().numpy()
+    unv = 20 * np.log10(1 - 1e-12)
+    assert bap.max() <= 0.0 + 1e-9 and bap[bap != unv].min() >= -60.0 - 1e-6
+    assert float(in_signal.abs().max()) <= 0.1 + 1e-6                       # sine_amp, no noise given
+    # batch independence (item 5 alone)
+    _, c1, _, f1 = an(wave[5:6].contiguous(), n[5:6], lf0[5:6])
+    assert torch.equal(c1[0], c[5]) and torch.equal(f1["bap"][0], feats["bap"][5])
+    assert torch.equal(f1["mcep"][0], feats["mcep"][5]) and torch.equal(f1["cf0"][0], feats["cf0"][5])
+    # scale: x -> 2 x
+    _, _, _, f2 = an((2.0 * wave).contiguous(), n, lf0)
+    d = (f2["mcep"] - feats["mcep"]).cpu().numpy()
+    assert np.abs(d[..., 0] - np.log(2.0)).max() < 1e-6 and np.abs(d[..., 1:]).max() < 1e-6
+    voiced_same = (f2["bap"] == unv).all(-1) == (feats["bap"] == unv).all(-1)
+    assert voiced_same.float().mean() > 0.999                               # Love-Train shares are scale-free
+    keep = voiced_same.cpu().numpy()
+    assert np.abs(f2["bap"].cpu().numpy()[keep] - bap[keep]).max() < 1e-6
+    assert torch.equal(f2["cf0"], feats["cf0"]) and torch.equal(f2["uv"], feats["uv"])
+
+
+@pytest.mark.gpu
 def test_gpu_all_unvoiced_item_is_flagged():
     x = (0.05 * np.random.default_rng(0).standard_normal(4800)).astype(np.float32)
     an = world.Analyzer()
