@@ -105,7 +105,7 @@ typedef struct SrnConvParams {
   int32_t precision;  /* SRN_PREC_* */
   int32_t no_halo;    /* kernel selection behind this entry point (testing / A-B timing): 0 = automatic, 1 = tiled kernels
                        * only (no halo, no strip), 2 = halo kernel whenever eligible, 3 = generic conv_gemm kernel only,
-                       * 4 = strip kernel whenever eligible */
+                       * 4 = strip kernel whenever eligible, 5 = exact fp32 on conv_fast.hip's loop instead of conv_f32.hip's */
   /* ws / ws_bytes: optional caller-owned workspace (16-byte aligned, at least srn_conv_gemm_workspace_bytes(p)
    * bytes, shared by all calls of one stream).  With it, launches whose tile grid cannot fill the chip are split
    * over K (conv_splitk.hip); without it (NULL) they run unsplit.  Results agree to fp32 summation order.

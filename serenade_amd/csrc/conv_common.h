@@ -256,6 +256,8 @@ __device__ __forceinline__ void splitk_store(const SrnConvParams& p, f32x16 (&ac
 int srn_conv_halo_try(const SrnConvParams& p, int tile, hipStream_t stream);
 // implemented in conv_fast.hip: lean split-bf16 kernel for C_in % 32 == 0, k-major weights.  Same return codes.
 int srn_conv_fast_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit = 1);
+// implemented in conv_f32.hip: the exact-fp32 contraction with a VALU-free main loop (tile ids 7, 9, 10).  Same return codes.
+int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit);
 // implemented in conv_splitk.hip: K slices for launches that cannot fill the chip (1 = do not split), the workspace
 // they need, and the reduction + epilogue over the partial sums.
 int srn_splitk_plan(const SrnConvParams& p);

@@ -458,7 +458,16 @@ int pick_tile(const SrnConvParams& p) {
     const int64_t blocks9 = rows * ((p.N + 127) / 128), blocks7 = rows * ((p.N + 63) / 64);
     if (p.geglu && blocks9 >= 512) return 9;
     if (p.N % 128 == 0 && p.N <= 256 && blocks9 >= 512) return 9;
-    if (!p.geglu && p.N % 64 == 0 && blocks7 >= 512) return 7;
+    if (!p.geglu && p.N % 64 == 0 && blocks7 >= 512) {
+      // every tile of the launch is co-resident (<= 6 per CU): the launch lasts as long as the fullest CU.  640 tiles
+      // of 64 x 64 (5120 rows x 512 columns: the half-resolution levels) are 3 on some CUs and 2 on others; the same
+      // output as 32 x 64 tiles (id 10, conv_f32.hip) is 5 on every CU
+      const int64_t blocks10 = 2 * blocks7;
+      if (blocks10 <= 6 * 256 && p.T_out % 32 == 0 &&
+          1.05 * 0.5 * (double)((blocks10 + 255) / 256) < (double)((blocks7 + 255) / 256))
+        return 10;
+      return 7;
+    }
   }
   float best = -1.f;
   int best_id = 4;
@@ -559,11 +568,16 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
     if (r != 0) return r < 0 ? r : 0;
   }
   if (p.no_halo != 3) {  // 3: generic kernel only (testing / A-B timing)
+    if (p.precision == SRN_PREC_FP32 && p.no_halo != 5) {  // 5: conv_fast.hip's fp32 form (A-B timing against conv_f32.hip)
+      const int r = srn_conv_f32_try(p, tile, stream, 1);
+      if (r != 0) return r < 0 ? r : 0;
+    }
+    if (tile == 10) tile = 7;  // the split-step tile exists only in conv_f32.hip
     const int r = srn_conv_fast_try(p, tile, stream);
     if (r != 0) return r < 0 ? r : 0;
   }
   // single-stage ids exist only in conv_fast.hip: their two-stage twins here
-  tile = tile == 6 ? 1 : tile == 7 ? 4 : tile == 8 ? 2 : tile == 9 ? 3 : tile;
+  tile = tile == 6 ? 1 : (tile == 7 || tile == 10) ? 4 : tile == 8 ? 2 : tile == 9 ? 3 : tile;
   if (p.w_nmajor) {
     switch (tile) {
       case 1: return launch<Cfg<128, 128, 64, 64, true>>(p, stream);

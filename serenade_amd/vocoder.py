@@ -20,7 +20,7 @@ import yaml
 
 from . import _shapes, ops
 from .models import _Packed, _dev_f32, _fold_wn, _lru_get, _require_cuda
-from .ops import ACT_LEAKY, POST_DIV, RES_ADD, ConvOp
+from .ops import ACT_LEAKY, POST_DIV, POST_LEAKY, RES_ADD, ConvOp
 
 __all__ = ["HiFiGANGenerator", "Vocoder", "load_vocoder", "hifigan_state_shapes"]
 
@@ -220,11 +220,13 @@ class HiFiGANPlan:
                                                 n_batch=B, T=Tn, C=C, k=cv["k"], dilation=cv["d"], slope=slope,
                                                 res2=fin.get("res2"), post_div=fin.get("post_div", 0.0)))
                     elif "w2" in cv:
+                        # the second LeakyReLU (residual_block.py:252) has one consumer: it runs once per element in
+                        # conv1's epilogue, not once per element per 32-deep step per column tile in conv2's loop (on
+                        # the fp32 matrix pipe every vector instruction of the loop is taken from the MFMA stream)
                         ol.append(conv(x, C, Tn, cv["w1"], cv["b1"], xt, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
-                                       pro_act=ACT_LEAKY, pro_slope=slope))
+                                       pro_act=ACT_LEAKY, pro_slope=slope, post=POST_LEAKY, post_div=slope))
                         ol.append(conv(xt, C, Tn, cv["w2"], cv["b2"], dst, C, Tn, ops.conv_taps(cv["k"], 1),
-                                       pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,
-                                       ld_res=C, **fin))
+                                       res=x, res_mode=RES_ADD, res_bs=Tn * C, ld_res=C, **fin))
                     else:
                         ol.append(conv(x, C, Tn, cv["w1"], cv["b1"], dst, C, Tn, ops.conv_taps(cv["k"], cv["d"]),
                                        pro_act=ACT_LEAKY, pro_slope=slope, res=x, res_mode=RES_ADD, res_bs=Tn * C,

@@ -86,7 +86,8 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
     tol = KTOL.k if tol is None else tol
     # two kernel families behind the one entry point: the specialised ones (conv_fast / halo / strip; auto) and the
     # generic conv_gemm kernel (no_halo=3 forces it)
-    variants = ("auto", "generic")
+    # (exact fp32 has two implementations of the specialised loop: conv_f32.hip, and conv_fast.hip's behind no_halo=5)
+    variants = ("auto", "generic", "fast_fp32")
     for tile, variant in [(t, u) for t in tiles for u in variants]:
         cpu = {}
         memo = {}
@@ -109,6 +110,10 @@ def run_conv_both(dev, kw, tol=None, tiles=(0,)):
             if gpu.get("no_halo"):
                 continue
             gpu["no_halo"] = 3
+        if variant == "fast_fp32":
+            if gpu.get("no_halo") or serenade_amd.get_precision() != "fp32":
+                continue
+            gpu["no_halo"] = 5
         op = ops.ConvOp(**gpu)
         op()
         torch.cuda.synchronize()
@@ -124,7 +129,7 @@ def rnd(*s, seed=0):
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(s).astype(np.float32))
 
 
-ALL_TILES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)  # 6-9: the single-LDS-stage forms
+ALL_TILES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)  # 6-9: the single-LDS-stage forms; 10: 32 x 64, step split over wave pairs
 
 
 def test_library_exports_and_error_path(dev):
