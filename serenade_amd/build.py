@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libserenade_hip.so")
-SOURCES = ["conv_gemm.hip", "conv_halo.hip", "conv_fast.hip", "conv_f32.hip", "conv_splitk.hip", "conv_strip.hip", "resunit.hip", "norm_act.hip", "gst.hip", "features.hip", "train.hip", "gst_train.hip", "tn_gemm.hip", "world.hip", "api.cpp"]
+SOURCES = ["conv_gemm.hip", "conv_halo.hip", "conv_fast.hip", "conv_f32.hip", "conv_splitk.hip", "conv_strip.hip", "resunit.hip", "resunit_f32.hip", "norm_act.hip", "gst.hip", "features.hip", "train.hip", "gst_train.hip", "tn_gemm.hip", "world.hip", "api.cpp"]
 
 
 def _hipcc():

@@ -21,6 +21,11 @@
 #include "conv_common.h"
 #include "serenade_hip.h"
 
+#include <stdlib.h>
+
+// implemented in resunit_f32.hip: 1 handled, 0 not eligible, < 0 error
+int srn_resunit_f32_try(const SrnResUnitParams& p, hipStream_t stream);
+
 namespace {
 
 constexpr int RU_HALO_MAX = 50;  // (k - 1) * dilation of the widest unit on the path (k 11, d 5)
@@ -410,7 +415,16 @@ extern "C" int srn_hifigan_resunit(const SrnResUnitParams* pp, void* stream_) {
     SRN_CHECK_ARG(p.w1_hi && p.w2_hi, "resunit: split-bf16 mode needs the weight planes w1_hi / w2_hi");
     return p.C == 32 ? launch_resunit<RCfg<32, 1>>(p, stream) : launch_resunit<RCfg<64, 1>>(p, stream);
   }
-  // exact fp32: eight waves per workgroup (A/B on the B = 8 x T = 1024 vocoder, 4 -> 8 waves: k 3 units 0.62 -> 0.51 ms,
+  // exact fp32: resunit_f32.hip's form of this kernel (same results bit for bit, ~no vector-ALU work beside the fp32
+  // MFMAs); SERENADE_AMD_RESUNIT_SHARED_FP32=1 keeps this file's instantiation (A-B timing, bit-identity test)
+  {
+    const char* e = getenv("SERENADE_AMD_RESUNIT_SHARED_FP32");
+    if (!(e && e[0] == '1')) {
+      const int r = srn_resunit_f32_try(p, stream);
+      if (r != 0) return r < 0 ? r : 0;
+    }
+  }
+  // eight waves per workgroup (A/B on the B = 8 x T = 1024 vocoder, 4 -> 8 waves: k 3 units 0.62 -> 0.51 ms,
   // k 7 1.17 -> 1.05, k 11 1.74 -> 1.61 at C = 64; all 18 units 16.7 -> 14.9 ms)
   return p.C == 32 ? launch_resunit<RCfg<32, 0, 8>>(p, stream) : launch_resunit<RCfg<64, 0, 8>>(p, stream);
 }

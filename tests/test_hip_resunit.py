@@ -84,6 +84,33 @@ def test_resunit_vs_conv1d(dev, C, k, d):
         assert guard.abs().max().item() == 0
 
 
+@pytest.mark.parametrize("C", [32, 64])
+def test_resunit_fp32_forms_agree_bit_for_bit(dev, C, monkeypatch):
+    """exact fp32 has two implementations of the fused unit: resunit_f32.hip (buffer addressing, no vector-ALU work beside
+    the fp32 MFMAs) and resunit.hip's instantiation (SERENADE_AMD_RESUNIT_SHARED_FP32=1): same LDS image, same MFMA order,
+    same epilogue order -- every unit of the path, sequence ends inside / across tiles, must agree bit for bit"""
+    if serenade_amd.get_precision() != "fp32":
+        pytest.skip("fp32 arm only")
+    slope = 0.1
+    for (k, d) in [(3, 1), (3, 5), (7, 3), (11, 5)]:
+        for case, (B, T, with_sum) in enumerate([(2, 37, False), (3, 2 * (256 - (k - 1)) + 1, True), (2, 1531, True)]):
+            x = rnd(B, T, C, seed=case + 1).to(dev)
+            w1 = ops.pack_conv_weight(rnd(C, C, k, seed=case + 2, scale=1.0 / np.sqrt(C * k)).to(dev))
+            w2 = ops.pack_conv_weight(rnd(C, C, k, seed=case + 3, scale=1.0 / np.sqrt(C * k)).to(dev))
+            b1, b2 = rnd(C, seed=case + 4, scale=0.1).to(dev), rnd(C, seed=case + 5, scale=0.1).to(dev)
+            res2 = rnd(B, T, C, seed=case + 6).to(dev) if with_sum else None
+            outs = []
+            for shared in ("0", "1"):
+                monkeypatch.setenv("SERENADE_AMD_RESUNIT_SHARED_FP32", shared)
+                out = torch.full((B, T, C), float("nan"), device=dev)
+                ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=out, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope,
+                              res2=res2, post_div=3.0 if with_sum else 0.0)()
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]), f"C={C} k={k} d={d} case {case}"
+
+
 def test_resunit_matches_the_unfused_pair_and_rejects_bad_args(dev):
     """same unit as two srn_conv_gemm launches (the round-1 path) and as one fused launch"""
     B, T, C, k, d, slope = 2, 700, 64, 7, 3, 0.1

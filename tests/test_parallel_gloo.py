@@ -174,3 +174,69 @@ def test_estimator_gradient_allreduce_gloo_world2():
         p.join(300)
         assert p.exitcode == 0
     assert err < 1e-6
+
+
+def _worker8(rank, world, port, q):
+    """BASELINE configs[3]: 64 utterances sharded 8-way, waveforms gathered on rank 0.  Sample (u, t) of utterance u is
+    u + t / 2^20 (exact in fp32), so reassembly in utterance order can be checked sample for sample."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, n = 64, 2400  # 64 utterances x 10 frames of 240 samples (the headline's T = 1024 would be 245 760 samples each)
+    a, b = shard_range(total, rank, world)
+    ramp = torch.arange(4096, dtype=torch.float32) / 1048576.0
+    wave = torch.stack([ramp[:n] + float(u) for u in range(a, b)])
+    out = gather_waveforms(wave, dst=0, uniform=True)  # the benchmark's form: one collective, no shape exchange
+    # ragged: 61 utterances (ranks 0-4 get 8, ranks 5-7 get 7), every utterance its own length, padded per rank
+    a2, b2 = shard_range(61, rank, world)
+    lens = torch.tensor([1200 + 37 * u for u in range(a2, b2)], dtype=torch.int64)
+    nmax = int(lens.max())
+    w2 = torch.zeros(b2 - a2, nmax)
+    for i, u in enumerate(range(a2, b2)):
+        w2[i, : lens[i]] = ramp[: lens[i]] + float(u)
+    out2 = gather_waveforms(w2, lens, dst=0)
+    if rank == 0:
+        # numpy arrays travel by value (a tensor would travel as a shared-memory handle that dies with this process)
+        q.put((torch.cat(out[0]).numpy(), [x.tolist() for x in out[1]], [w.numpy().copy() for w in out2[0]],
+               [x.tolist() for x in out2[1]]))
+    else:
+        assert out is None and out2 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_partitioning_gloo_world8():
+    """world size 8 on the CPU: the contiguous 8-way split of 64 utterances and the gather's rank order / sample-exact
+    reassembly (uniform and ragged), which world size 2 does not cover"""
+    assert [shard_range(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    import time
+    t_end = time.time() + 240
+    while q.empty() and time.time() < t_end and all(p.exitcode in (None, 0) for p in procs):
+        time.sleep(0.2)
+    if q.empty():  # a rank died or hung: do not leave its peers waiting in a collective
+        for p in procs:
+            p.kill()
+        raise AssertionError(f"no result from rank 0 (exit codes {[p.exitcode for p in procs]})")
+    full, ns, ragged, rns = q.get()
+    full, ragged = torch.from_numpy(full), [torch.from_numpy(w) for w in ragged]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ramp = torch.arange(4096, dtype=torch.float32) / 1048576.0
+    assert tuple(full.shape) == (64, 2400) and ns == [[2400] * 8] * 8
+    assert torch.equal(full, ramp[None, :2400] + torch.arange(64, dtype=torch.float32)[:, None])
+    assert [len(x) for x in rns] == [8, 8, 8, 8, 8, 7, 7, 7]
+    u = 0
+    for w, lens in zip(ragged, rns):
+        for i, n in enumerate(lens):
+            assert n == 1200 + 37 * u
+            assert torch.equal(w[i, :n], ramp[:n] + float(u)) and (w[i, n:] == 0).all()
+            u += 1
+    assert u == 61
