@@ -175,8 +175,9 @@ def cpu_baseline(sd, gsd):
     box's host cores, fp32 torch CPU, same synthetic inputs, bounded samples (SURVEY section 8d / BASELINE.md 4):
       * all usable physical cores: ONE utterance of the headline workload (T=1024, T_ref=256, 10 Euler steps +
         HiFi-GAN) -- 1 warm-up on a short clip, median of 3;
-      * 1 thread (the recipe's OMP_NUM_THREADS=1, egs/gtsinger/ssc1/path.sh:16): ONE utterance of the C1 shape
-        (T=256, T_ref=256) -- median of 3."""
+      * 1 thread (the recipe's OMP_NUM_THREADS=1, egs/gtsinger/ssc1/path.sh:16): the SAME utterance (T=1024), one
+        timed run (~17 s), so the two legs can be set side by side; the C1 shape (T=256, T_ref=256) on one
+        thread as before, median of 3."""
     from oracle import serenade_oracle as O
     from serenade_amd.utils.synth import HIFIGAN_PARAMS, synth_inputs
     t1 = torch.ones(80)
@@ -196,11 +197,12 @@ def cpu_baseline(sd, gsd):
     warm = synth_inputs(1, 64, T_ref=32, seed=7)
     legs = {}
     try:
-        for name, threads, T in (("all_cores", n_all, 1024), ("one_thread", 1, 256)):
+        for name, threads, T, reps in (("all_cores", n_all, 1024, 3), ("one_thread", 1, 1024, 1),
+                                       ("one_thread_c1_shape", 1, 256, 3)):
             torch.set_num_threads(threads)
             d = synth_inputs(1, T, T_ref=256, seed=1235)
             run(warm)
-            ts = [run(d) for _ in range(3)]
+            ts = [run(d) for _ in range(reps)]
             med = statistics.median(ts)
             legs[name] = {"value": T / med, "unit": "frames/s", "threads": threads, "median_s": med,
                           "runs_s": [round(t, 3) for t in ts],
@@ -210,7 +212,8 @@ def cpu_baseline(sd, gsd):
     a = legs["all_cores"]
     return {"value": a["value"], "unit": "frames/s", "cores": a["threads"], "kind": "port",
             "sample": a["sample"] + f"; fp32 torch CPU, 1 warm-up, median of 3 ({a['median_s']:.1f} s)",
-            "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "one_thread": legs["one_thread"]}
+            "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "one_thread": legs["one_thread"],
+            "one_thread_c1_shape": legs["one_thread_c1_shape"]}
 
 
 def cpu_train_baseline(sd, B=1, L=256):
@@ -399,8 +402,11 @@ def main():
         same_workload = (B_PER_GPU, T_SRC, T_REF, N_EULER) == (8, 1024, 256, 10)
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": tr["bytes_per_launch"] if (tr and same_workload) else None,
-                "kernel": f"srn_conv_gemm<{precision}> implicit-GEMM contraction kernels (conv_fast / conv_halo / "
-                          f"conv_strip / conv_gemm, all tiles)",
+                # the same algorithmic FLOPs over the WHOLE driver-timed step (small kernels, launch gaps, host included)
+                "frac_of_step": fl / (elapsed / args.steps) / 1e12 / peak,
+                "achieved_of_step": fl / (elapsed / args.steps) / 1e12,
+                "kernel": f"srn_conv_gemm<{precision}> implicit-GEMM contraction kernels (conv_f32 / conv_fast / conv_halo "
+                          f"/ conv_strip / conv_gemm, all tiles) + srn_hifigan_resunit",
                 "launches_per_step": n_launch, "avg_launch_us": (durs.mean() * 1e3) if len(durs) else 0.0,
                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
                 "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),

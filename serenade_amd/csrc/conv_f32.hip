@@ -47,9 +47,9 @@ struct F32Launch {
 };
 
 // KW: groups of waves that split every 32-deep step between them (each group owns the whole BM x BN tile)
-template <int BM_, int BN_, int WM_, int WN_, int KW_, int MINW_>
+template <int BM_, int BN_, int WM_, int WN_, int KW_, int MINW_, int PF_ = 1>
 struct TCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KW = KW_, MINW = MINW_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KW = KW_, MINW = MINW_, PF = PF_;
   static constexpr int MT = WM / 32, NT = WN / 32;
   static constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
   static_assert(WAVES_M * WAVES_N * KW == 4, "4 waves per workgroup");
@@ -387,7 +387,41 @@ __global__ __launch_bounds__(256, C::MINW) void conv_f32_kernel(const SrnConvPar
 
   // One LDS stage, one register set: [write tile s | barrier | loads of tile s+1 issued, MFMAs of tile s | barrier].
   // Nothing overlaps inside the workgroup; the co-resident workgroups overlap each other (conv_fast.hip, NSTAGE = 1).
-  if (n_steps > 0) {
+  if constexpr (C::PF == 2) {
+    // two register sets: the loads of step s + 2 are issued inside step s.  For grids that leave a workgroup alone on
+    // its CU (B = 1, split-K slices): nothing else covers a step's memory latency there
+    Regs R0, R1;
+    auto step = [&](Regs& R, const bool more) {
+      store(R);
+      __syncthreads();
+      if (more) load_issue(R);
+      compute();
+      if (more) advance();
+      __syncthreads();
+    };
+    if (n_steps == 1) {
+      load_issue(R0);
+      step(R0, false);
+    } else if (n_steps > 1) {
+      load_issue(R0);
+      advance();
+      load_issue(R1);
+      advance();
+      int s = 0;
+      for (; s + 3 < n_steps; s += 2) {
+        step(R0, true);
+        step(R1, true);
+      }
+      if (n_steps - s == 3) {
+        step(R0, true);
+        step(R1, false);
+        step(R0, false);
+      } else {
+        step(R0, false);
+        step(R1, false);
+      }
+    }
+  } else if (n_steps > 0) {
     Regs R;
     load_issue(R);
     advance();
@@ -473,7 +507,8 @@ int launch_f32(const SrnConvParams& p, hipStream_t stream, const int ksplit) {
 
 // Returns 1 if the launch was handled, 0 if the shape is not eligible (the caller goes on to conv_fast.hip), < 0 on
 // error.  `p` has been validated and defaulted by srn_conv_gemm.  Tile ids: 7 = 64 x 64, 9 = 64 x 128 (conv_fast.hip's
-// single-stage ids, same results bit for bit), 10 = 32 x 64 with the step split over two wave pairs.
+// single-stage ids, same results bit for bit), 10 = 32 x 64 with the step split over two wave pairs, 11 = 64 x 64 with
+// two register sets (loads two steps ahead: small grids and split-K slices, where a workgroup is alone on its CU).
 int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit) {
   if (p.precision != SRN_PREC_FP32 || p.w_nmajor) return 0;
   if (p.C_in % BK != 0 || p.C_in0 % BK != 0) return 0;
@@ -493,6 +528,7 @@ int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int k
     case 7: return launch_f32<TCfg<64, 64, 32, 32, 1, 6>>(p, stream, ksplit);
     case 9: return launch_f32<TCfg<64, 128, 32, 64, 1, 4>>(p, stream, ksplit);
     case 10: return p.geglu ? 0 : launch_f32<TCfg<32, 64, 32, 32, 2, 6>>(p, stream, ksplit);
+    case 11: return launch_f32<TCfg<64, 64, 32, 32, 1, 5, 2>>(p, stream, ksplit);
     default: return 0;
   }
 }

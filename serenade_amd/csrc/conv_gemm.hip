@@ -552,7 +552,11 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
     // small grids with a deep contraction (B = 1 / short utterances): slice K over extra workgroups, reduce after
     const int ks = srn_splitk_plan(p);
     if (ks > 1 && p.ws_bytes >= srn_splitk_bytes(p, ks)) {
-      const int r = srn_conv_fast_try(p, 4, stream, ks);
+      // exact fp32: conv_f32.hip's 64 x 64 tile with loads two steps ahead (id 11; B = 1 x T = 256: 16.8 -> 15.8 ms
+      // against conv_fast.hip's double-buffered tile here and for the unsplit small grids below)
+      int r = 0;
+      if (p.precision == SRN_PREC_FP32 && p.no_halo != 5) r = srn_conv_f32_try(p, 11, stream, ks);
+      if (r == 0) r = srn_conv_fast_try(p, 4, stream, ks);
       if (r < 0) return r;
       if (r == 1) return srn_splitk_reduce(p, ks, stream);
     }
@@ -569,15 +573,16 @@ extern "C" int srn_conv_gemm(const SrnConvParams* pp, void* stream_) {
   }
   if (p.no_halo != 3) {  // 3: generic kernel only (testing / A-B timing)
     if (p.precision == SRN_PREC_FP32 && p.no_halo != 5) {  // 5: conv_fast.hip's fp32 form (A-B timing against conv_f32.hip)
-      const int r = srn_conv_f32_try(p, tile, stream, 1);
+      const int r = srn_conv_f32_try(p, tile == 4 ? 11 : tile, stream, 1);  // 4: small grids -> its two-steps-ahead form
       if (r != 0) return r < 0 ? r : 0;
     }
     if (tile == 10) tile = 7;  // the split-step tile exists only in conv_f32.hip
+    if (tile == 11) tile = 4;  // ... and so does the two-steps-ahead tile: conv_fast.hip's double-buffered twin
     const int r = srn_conv_fast_try(p, tile, stream);
     if (r != 0) return r < 0 ? r : 0;
   }
   // single-stage ids exist only in conv_fast.hip: their two-stage twins here
-  tile = tile == 6 ? 1 : (tile == 7 || tile == 10) ? 4 : tile == 8 ? 2 : tile == 9 ? 3 : tile;
+  tile = tile == 6 ? 1 : (tile == 7 || tile == 10 || tile == 11) ? 4 : tile == 8 ? 2 : tile == 9 ? 3 : tile;
   if (p.w_nmajor) {
     switch (tile) {
       case 1: return launch<Cfg<128, 128, 64, 64, true>>(p, stream);

@@ -189,6 +189,166 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const SrnTnGemmParams p
     }
 }
 
+// The same kernel with its operand walk on the scalar unit (round 4): v_mfma_f32_32x32x2_f32 shares the SIMD's fp32 lanes
+// with ordinary vector instructions (conv_f32.hip), and the general kernel above spends ~80 of them per 32-MFMA step on
+// 64-bit row pointers, bounds compares and selects.  When every 16-row slab lies inside ONE item (T_a % 16 == 0, one-level
+// items) the item, the row inside it and both tensors' descriptors are wave-uniform: A is fetched with a constant per-lane
+// offset and the row in the scalar offset, B with one add per load (its row must sit in the per-lane offset: rows outside
+// [0, len_b) then fall outside the item's descriptor and read as zeros -- "same" padding and the x * mask without a compare).
+// LDS image, fragment reads, MFMA order, column sums and epilogue are the general kernel's: results agree bit for bit.
+template <int TB>
+__global__ __launch_bounds__(256, 2) void tn_lean_kernel(const SrnTnGemmParams p, const int m_tiles, const int n_tiles,
+                                                         const int ksplit, const int k_per) {
+  constexpr int BM = TB, BN = TB;
+  constexpr int PITCH = (2 * 2 * BK * (TB + 4) * 4 > 65536) ? TB : TB + 4;
+  constexpr int SLAB = BK * PITCH;
+  constexpr int WT = TB / 64;
+  constexpr int F4 = TB / 4;
+  constexpr int ROWS_PER_PASS = 256 / F4;
+  constexpr int NLD = BK / ROWS_PER_PASS;
+  typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float lds[2][2][SLAB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x / m_tiles, mt = blockIdx.x - nt * m_tiles;  // (scalar divisions: once per workgroup)
+  const int tap = blockIdx.y;
+  const int z = blockIdx.z / ksplit, slice = blockIdx.z - z * ksplit;
+  const int zb = z / p.n_head, zh = z - zb * p.n_head;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int shift = p.shift[tap];
+  const float* A = p.a + (int64_t)zb * p.a_bs + (int64_t)zh * p.a_hs;
+  const float* Bm = p.b + (int64_t)zb * p.b_bs + (int64_t)zh * p.b_hs;
+  const int K = p.n_items * p.T_a;
+  const int k_begin = slice * k_per, k_end = min(K, k_begin + k_per);
+  const int n_steps = k_end > k_begin ? (k_end - k_begin) / BK : 0;
+
+  const int lrow = tid / F4;
+  const int lcol = (tid % F4) * 4;
+  const unsigned OOBT = 0x80000000u;
+  // the next slab to fetch: item, first row inside it (wave-uniform); descriptors of that item
+  int item = k_begin / p.T_a;
+  int t0 = k_begin - item * p.T_a;
+  const int a_bytes = ((p.T_a - 1) * p.lda + (p.M + 3) / 4 * 4) * 4;
+  unsigned voff_a[NLD], voff_b[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i)
+    voff_a[i] = m0 + lcol < p.M ? (unsigned)(((lrow + ROWS_PER_PASS * i) * p.lda + m0 + lcol) * 4) : OOBT;
+  const int b_row_step = BK * p.stride * p.ldb * 4;
+  auto seat_b = [&]() {  // per-lane offsets of b's rows for the slab at (item, t0)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int tb = (t0 + lrow + ROWS_PER_PASS * i) * p.stride + shift;
+      voff_b[i] = n0 + lcol < p.N ? (unsigned)((tb * p.ldb + n0 + lcol) * 4) : OOBT;  // tb < 0 wraps past 2^31: zeros
+    }
+  };
+  seat_b();
+  u32x4t ra[NLD], rb[NLD];
+  auto load = [&]() {  // fetch the slab at (item, t0), then advance one slab
+    const int it = min(item, p.n_items - 1);
+    const int lend = p.len_b != nullptr ? min(p.T_b, p.len_b[zb * p.n_items + it]) : p.T_b;
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (int64_t)it * p.a_is), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bm + (int64_t)it * p.b_is), 0, lend * p.ldb * 4, 0x00020000);
+    const int soff_a = t0 * p.lda * 4;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff_a[i], soff_a, 0);
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b[i], 0, 0);
+    }
+    t0 += BK;
+    if (t0 >= p.T_a) {
+      t0 = 0;
+      ++item;
+      seat_b();
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) voff_b[i] += b_row_step;
+    }
+  };
+  auto store = [&](const int st) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      *reinterpret_cast<u32x4t*>(&lds[st][0][(lrow + ROWS_PER_PASS * i) * PITCH + lcol]) = ra[i];
+      *reinterpret_cast<u32x4t*>(&lds[st][1][(lrow + ROWS_PER_PASS * i) * PITCH + lcol]) = rb[i];
+    }
+  };
+
+  const int wm0 = (wave >> 1) * (TB / 2), wn0 = (wave & 1) * (TB / 2);
+  const int fm = lane & 31, fk = lane >> 5;
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const bool do_cs = p.colsum != nullptr && nt == 0 && tap == 0;
+  float csum = 0.f;
+  if (n_steps > 0) {
+    load();
+    store(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < n_steps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < n_steps) load();
+    const float* la = &lds[cur][0][0];
+    const float* lb = &lds[cur][1][0];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int row = (kk + fk) * PITCH;
+      float av[WT], bv[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        av[i] = la[row + wm0 + 32 * i + fm];
+        bv[i] = lb[row + wn0 + 32 * i + fm];
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_cs && tid < TB) {
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) csum += la[kk * PITCH + tid];
+    }
+    if (s + 1 < n_steps) store(cur ^ 1);
+    __syncthreads();
+  }
+  if (do_cs && tid < TB && m0 + tid < p.M) {
+    if (ksplit > 1)
+      p.ws[(int64_t)ksplit * p.n_batch * p.n_head * p.M * p.n_shifts * p.N + (int64_t)slice * p.M + m0 + tid] = csum;
+    else
+      p.colsum[m0 + tid] = csum * p.alpha;
+  }
+
+  float* out;
+  int64_t ld;
+  float alpha = 1.f;
+  if (ksplit > 1) {
+    ld = (int64_t)p.n_shifts * p.N;
+    out = p.ws + (((int64_t)slice * p.n_batch * p.n_head + z) * p.M) * ld + (int64_t)tap * p.N;
+  } else {
+    ld = p.ldc;
+    out = p.out + (int64_t)zb * p.out_bs + (int64_t)zh * p.out_hs + (int64_t)tap * p.N;
+    alpha = p.alpha;
+  }
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int col = n0 + wn0 + 32 * j + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.M) out[(int64_t)row * ld + col] = acc[i][j][e] * alpha;
+      }
+    }
+}
+
 // out[z][m][:] = alpha * sum_s ws[s][z][m][:], slices in order; one float4 per thread
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const SrnTnGemmParams p, const int ksplit) {
   const int64_t cols = (int64_t)p.n_shifts * p.N;  // % 4 == 0
@@ -307,7 +467,15 @@ extern "C" int srn_tn_gemm(const SrnTnGemmParams* pp, void* stream_) {
   const int64_t gz = (int64_t)p.n_batch * p.n_head * ks;
   SRN_CHECK_ARG(gz <= 65535 && (int64_t)m_tiles * n_tiles < (1ll << 31), "tn_gemm: grid too large");
   const dim3 grid(m_tiles * n_tiles, p.n_shifts, (unsigned)gz);
-  auto kern = TB == 64 ? tn_gemm_kernel<64> : tn_gemm_kernel<128>;
+  // the scalar-walk form: every slab inside one item, 32-bit byte offsets inside an item (SRN_TN_GENERAL=1: A-B timing
+  // and the bit-identity test keep the general kernel)
+  const char* const env_general = getenv("SRN_TN_GENERAL");
+  const bool general_only = env_general != nullptr && env_general[0] == '1';
+  const bool lean = !general_only && p.n_inner <= 1 && p.T_a % BK == 0 && k_per % BK == 0 &&
+                    (int64_t)p.T_a * p.lda * 4 < 0x7fffffffll &&
+                    ((int64_t)p.T_b + (int64_t)p.T_a * p.stride + 64) * p.ldb * 4 < 0x7fffffffll;
+  auto kern = lean ? (TB == 64 ? tn_lean_kernel<64> : tn_lean_kernel<128>)
+                   : (TB == 64 ? tn_gemm_kernel<64> : tn_gemm_kernel<128>);
   hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, p, m_tiles, n_tiles, ks, k_per);
   if (ks > 1) {
     const int64_t n4 = (int64_t)p.n_batch * p.n_head * p.M * p.n_shifts * p.N / 4 + (p.colsum != nullptr ? p.M / 4 : 0);

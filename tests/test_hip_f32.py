@@ -1,7 +1,7 @@
 """GPU tests of conv_f32.hip, the exact-fp32 contraction with a vector-ALU-free loop (buffer loads, scalar K walk,
 out-of-range offsets for padded rows, magic-number tile coordinates; tile ids 7 / 9 / 10 in fp32).
 
-* tiles 7 and 9 keep conv_fast.hip's LDS image and MFMA order: results must be BIT-identical to its fp32 loop
+* tiles 7, 9 and 11 (64 x 64 with loads two steps ahead: small grids, split-K) keep conv_fast.hip's LDS image and MFMA order: results must be BIT-identical to its fp32 loop
   (no_halo=5) on every addressing feature of the path (taps, dilation, stride 2, reflection, two-tensor concat, item
   lengths, heads with strides, batched B operand, LeakyReLU prologue, residual / GroupNorm-partial epilogues);
 * tile 10 (32 x 64, each 32-deep step split over two wave pairs, partial sums joined through LDS) against F.conv1d in
@@ -74,7 +74,7 @@ def cases():
                                    out_bs=H * L * L, out_hs=L * L, ld_out=L, alpha=0.125)
 
 
-@pytest.mark.parametrize("tile", [7, 9])
+@pytest.mark.parametrize("tile", [7, 9, 11])
 def test_bit_identical_to_conv_fast_fp32(dev, tile):
     for name, kw in cases():
         a = run(dev, kw, tile=tile)

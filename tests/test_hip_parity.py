@@ -129,7 +129,7 @@ def rnd(*s, seed=0):
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(s).astype(np.float32))
 
 
-ALL_TILES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)  # 6-9: the single-LDS-stage forms; 10: 32 x 64, step split over wave pairs
+ALL_TILES = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)  # 11: 64 x 64, loads two steps ahead; 6-9: the single-LDS-stage forms; 10: 32 x 64, step split over wave pairs
 
 
 def test_library_exports_and_error_path(dev):

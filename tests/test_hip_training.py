@@ -453,6 +453,44 @@ def test_tn_gemm_against_fp64(dev, case):
         assert not out[:, :, :2 * H * hd].any()  # nothing outside the head slices was touched
 
 
+@pytest.mark.parametrize("case", ["wgrad_k3", "wgrad_stride2", "attn"])
+def test_tn_gemm_scalar_walk_form_is_bit_identical(dev, case, monkeypatch):
+    """slabs that lie inside one item (T_a % 16 == 0) take tn_lean_kernel (operand walk on the scalar unit, buffer loads,
+    out-of-range rows as zeros); SRN_TN_GENERAL=1 keeps the general kernel: same LDS image and MFMA order, so the same
+    bits -- with item lengths, the bias gradient riding along, stride 2 and head strides"""
+    from serenade_amd.ops import TnGemmOp
+    g = torch.Generator().manual_seed(len(case))
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    outs = []
+    if case.startswith("wgrad"):
+        B, T, C, N, taps, stride, T_out = {"wgrad_k3": (4, 512, 256, 512, (-1, 0, 1), 1, 512),
+                                           "wgrad_stride2": (3, 320, 128, 96, (-1, 0, 1), 2, 160)}[case]
+        x, dy = r(B, T, C), r(B, T_out, N)
+        lens = torch.tensor([max(1, T - 37 * i - 3) for i in range(B)], dtype=torch.int32).to(dev)
+        for general in ("0", "1"):
+            monkeypatch.setenv("SRN_TN_GENERAL", general)
+            dw = torch.full((N, len(taps) * C), float("nan"), device=dev)
+            db = torch.full((N,), float("nan"), device=dev)
+            TnGemmOp(out=dw, a=dy, b=x, n_items=B, T_a=T_out, T_b=T, M=N, N=C, lda=N, ldb=C, ldc=len(taps) * C, shifts=taps,
+                     stride=stride, a_is=T_out * N, b_is=T * C, len_b=lens, colsum=db)()
+            torch.cuda.synchronize()
+            outs.append((dw, db))
+        assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    else:
+        B, H, L, hd = 2, 4, 256, 64
+        P, do = r(B, H, L, L), r(B, L, H * hd)
+        for general in ("0", "1"):
+            monkeypatch.setenv("SRN_TN_GENERAL", general)
+            out = torch.zeros(B, L, 3 * H * hd, device=dev)
+            TnGemmOp(a=P, b=do, out=(out, 2 * H * hd), n_items=1, T_a=L, T_b=L, M=L, N=hd, lda=L, ldb=H * hd, ldc=3 * H * hd,
+                     n_batch=B, n_head=H, a_bs=H * L * L, a_hs=L * L, b_bs=L * H * hd, b_hs=hd, out_bs=L * 3 * H * hd,
+                     out_hs=hd, alpha=0.5)()
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert outs[0].abs().max() > 0 and torch.equal(outs[0], outs[1])
+
+
 # ---- fused weight norm + re-layout (the content encoder's convs) against torch autograd of the same expression
 @pytest.mark.parametrize("shape", [(96, 64, 3), (80, 768, 7), (512, 512, 1)])
 def test_weight_norm_pack_against_torch(dev, shape):

@@ -27,7 +27,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNEL_TAGS = ("conv_fast_kernel", "conv_halo_kernel", "conv_strip_kernel", "conv_gemm_kernel", "attn_", "resunit_")
+KERNEL_TAGS = ("conv_f32_kernel", "conv_fast_kernel", "conv_halo_kernel", "conv_strip_kernel", "conv_gemm_kernel", "attn_", "resunit_")
 SQ = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
       "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU"]
 

@@ -42,32 +42,50 @@ def main():
     print(f"SiFiGAN B={B} T={T} (5 ms frames): {el * 1e3:.2f} ms per batch = {sec / el:.0f}x real time, "
           f"{B * T / 2 / el:.0f} mel-frame equivalents (10 ms) per second")
     if "--ops" in sys.argv:
+        # per-op table (the a8 evidence of tools/opbench.py for row a9): every contraction by shape with its TFLOP/s, the
+        # HBM-bound gathers with their GB/s, and the generator's roofline line
         import collections
+        import json
         pl = list(g._plans.values())[0] if hasattr(g, "_plans") and g._plans else None
         if pl is not None:
-            agg = collections.OrderedDict()
-            for op in pl.ops:
-                if not isinstance(op, ops.ConvOp):
-                    continue
-                k = op.kw
-                key = (k["n_batch"], k["T_out"], k["N"], len(k.get("taps", (0,))) * k["C_in"], k.get("in_stride", 1))
+            def t_op(op, reps=5):
                 op()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                for _ in range(5):
+                for _ in range(reps):
                     op()
                 e.record()
                 torch.cuda.synchronize()
-                a = agg.setdefault(key, [0, 0.0])
+                return s.elapsed_time(e) / reps
+            agg, other = collections.OrderedDict(), collections.OrderedDict()
+            for op in pl.ops:
+                ms = t_op(op)
+                if isinstance(op, ops.ConvOp):
+                    k = op.kw
+                    key = (k["n_batch"], k["T_out"], k["N"], len(k.get("taps", (0,))) * k["C_in"], k.get("in_stride", 1),
+                           int(k.get("pro_act", 0)))
+                    a = agg.setdefault(key, [0, 0.0])
+                else:
+                    a = other.setdefault(type(op).__name__ + ":" + getattr(op, "name", ""), [0, 0.0])
                 a[0] += 1
-                a[1] += s.elapsed_time(e) / 5
+                a[1] += ms
             tot = sum(v[1] for v in agg.values())
-            print(f"conv ops: {tot:.2f} ms total")
-            for key, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
-                Z, To, N, K, st = key
-                print(f"  Z={Z} T={To:7d} N={N:4d} K={K:5d} stride={st} cnt={cnt:3d} {ms / cnt:7.3f} ms each "
-                      f"{2.0 * Z * To * N * K * cnt / ms / 1e9:6.1f} TF/s {100 * ms / tot:5.1f}%")
+            fl = sum(2.0 * k[0] * k[1] * k[2] * k[3] * c for k, (c, _) in agg.items())
+            print(f"contractions: {tot:.2f} ms for {fl / 1e9:.0f} GFLOP = {fl / tot / 1e9:.1f} TFLOP/s; other kernels "
+                  f"{sum(v[1] for v in other.values()):.2f} ms")
+            print("   Z   T_out     N      K str act | cnt  ms_each   TF/s  share")
+            for key, (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                Z, To, N, K, st, act = key
+                print(f"{Z:4d} {To:7d} {N:5d} {K:6d} {st:3d} {act:3d} | {cnt:3d} {ms / cnt:8.3f} "
+                      f"{2.0 * Z * To * N * K * cnt / ms / 1e9:6.1f} {100 * ms / tot:6.1f}%")
+            for name, (cnt, ms) in sorted(other.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {name:40s} cnt {cnt:3d}  {ms:7.3f} ms")
+            peak = 157.3 if os.environ.get("SERENADE_AMD_PRECISION", "bf16x3") == "fp32" else 2500.0
+            print(json.dumps({"sifigan_generator": {"ms_per_batch": el * 1e3, "contraction_ms": tot, "algorithmic_gflop": fl / 1e9,
+                                                    "roofline": {"bound": "mfma", "achieved": fl / tot / 1e9, "peak": peak,
+                                                                 "unit": "TFLOP/s", "frac": fl / tot / 1e9 / peak},
+                                                    "precision": os.environ.get("SERENADE_AMD_PRECISION", "bf16x3")}}))
 
 
 if __name__ == "__main__":
