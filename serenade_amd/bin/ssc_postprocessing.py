@@ -126,10 +126,17 @@ class PostJob:
         lo, hi = parallel.shard_range(len(files), rank, n_ranks)
         logger.info(f"Processing {self.cfg['in_dir']}: {hi - lo} of {len(files)} files on rank {rank}/{n_ranks}")
         frames, t0 = 0, time.time()
+        for key in ("mcap_dim", "f0_floor", "f0_ceil"):  # accepted like the reference's yaml, not used by this data flow
+            if self.cfg[key] != DEFAULTS[key]:
+                logger.warning(f"{key}={self.cfg[key]} has no effect here: the F0 comes from the decode CLI's lf0 and `mcap` "
+                               "is never consumed with aux_feats [mcep, bap] (ssc_postprocessing.py:147-170)")
         with torch.no_grad():
             for wav_file in files[lo:hi]:
                 logger.info(f"Start processing {wav_file}")
-                frames += self.process(wav_file)
+                try:
+                    frames += self.process(wav_file)
+                except (ValueError, NotImplementedError, OSError) as e:  # one bad file must not end the directory run
+                    logger.error(f"skipped {wav_file}: {e}")
         torch.cuda.synchronize()
         dt = max(time.time() - t0, 1e-9)
         logger.info(f"rank {rank}/{n_ranks}: {frames} analysis frames in {dt:.2f} s = {frames / dt:.1f} frames/s")

@@ -818,6 +818,11 @@ class Estimator:
         self._relay()
         B, _, L = x.shape
         maskb = mask.reshape(B, L) > 0
+        if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # the reference's `x * mask` is done by row counts here (len_in / len_out / len_b of the kernels): that equals
+            # the multiply only for a LENGTH mask -- anything else would silently change activations and gradients
+            if not torch.equal(maskb, torch.arange(L, device=x.device)[None] < maskb.sum(1, keepdim=True)):
+                raise ValueError("Estimator.forward: `mask` must be a length (prefix) mask, as make_non_pad_mask builds it")
         h = torch.cat([x, mu], dim=1).transpose(1, 2)  # (B, L, 242) channels-last
         cin = h.shape[-1]
         cp = _rup(cin, 32)
@@ -907,6 +912,10 @@ class _Dot(torch.autograd.Function):
     def forward(ctx, a, b):
         a = a.contiguous().view(-1)
         b = None if b is None else b.contiguous().view(-1)
+        if a.data_ptr() % 16:  # srn_dot reads 16-byte pieces: a sliced view may start anywhere
+            a = a.clone()
+        if b is not None and b.data_ptr() % 16:
+            b = b.clone()
         part = torch.zeros(1024, device=a.device, dtype=torch.float64)
         _call("srn_dot", a, b, a.numel(), part)
         ctx.save_for_backward(a, b)
@@ -1054,12 +1063,15 @@ class TrainSerenade:
         while f"{r}convs.{3 * i}.weight" in P:
             c, b = f"{r}convs.{3 * i}", f"{r}convs.{3 * i + 1}"
             h = conv2d_s2(h, P[c + ".weight"])
-            rm, rv = (Bf[b + ".running_mean"], Bf[b + ".running_var"]) if self.training else (None, None)
-            if not self.training:
-                raise NotImplementedError("TrainSerenade.gst runs BatchNorm on batch statistics (training mode)")
-            h = bn_relu(h, P[b + ".weight"], P[b + ".bias"], rm, rv)
-            if b + ".num_batches_tracked" in Bf:
-                Bf[b + ".num_batches_tracked"] += 1
+            if self.training:
+                h = bn_relu(h, P[b + ".weight"], P[b + ".bias"], Bf[b + ".running_mean"], Bf[b + ".running_var"])
+                if b + ".num_batches_tracked" in Bf:
+                    Bf[b + ".num_batches_tracked"] += 1
+            else:
+                # eval mode (the reference's _eval_epoch, trainers/base.py:171-190): BatchNorm2d on the running
+                # statistics, folded into one scale / shift per channel (channels last), then ReLU
+                scale = P[b + ".weight"] * torch.rsqrt(Bf[b + ".running_var"] + 1e-5)
+                h = torch.relu(h * scale + (P[b + ".bias"] - Bf[b + ".running_mean"] * scale))
             i += 1
         bsz, tlen, wdim, cdim = h.shape
         xs = h.reshape(bsz, tlen, wdim * cdim)  # features ordered (w, c); the reference's view orders them (c, w)

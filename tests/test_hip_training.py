@@ -205,6 +205,28 @@ def test_whole_model_gradients_match_the_reference(dev, golden):
     assert rel(model.buffers["gst.ref_enc.convs.16.running_var"].cpu(), torch.from_numpy(g["bn_var"])) < 1e-4
 
 
+def test_gst_eval_mode_runs_on_the_running_statistics(dev):
+    """with `training = False` (the reference's _eval_epoch calls model.eval(), trainers/base.py:171-190) the
+    training model's GST normalises with BatchNorm's RUNNING statistics -- the same numbers the inference StyleEncoder
+    produces from the same state_dict -- and leaves those statistics alone"""
+    from serenade_amd import models
+    from serenade_amd.utils.synth import SERENADE_PARAMS
+    w = serenade_weights()
+    tm = training.TrainSerenade(w, dev, dropout=0.0)
+    inf = models.Serenade(**SERENADE_PARAMS)
+    inf.load_state_dict(w)
+    inf = inf.eval().to(dev)
+    speech = torch.randn(2, 64, 80, generator=torch.Generator().manual_seed(3)).to(dev)
+    before = tm.buffers["gst.ref_enc.convs.1.running_mean"].clone()
+    tm.training = False
+    with torch.no_grad():
+        got = tm.gst(speech)
+    tm.training = True
+    ref = inf.gst(speech)
+    assert torch.equal(before, tm.buffers["gst.ref_enc.convs.1.running_mean"])
+    assert rel(got.cpu(), ref.cpu()) < 2e-5
+
+
 def test_training_loop_with_dropout_runs_and_learns(dev):
     """the real configuration (dropout 0.05, random draws): five whole-model steps on one batch -- finite, the loss
     falls, parameters of all three modules move, state_dict() round-trips into the inference model"""
