@@ -60,16 +60,16 @@ def sweep(oplist, reps=5):
     for op in oplist:
         if isinstance(op, ops.ConvOp) and sig(op.kw) not in seen:
             seen[sig(op.kw)] = op
-    print(f"{'Z':>4} {'T_out':>7} {'N':>5} {'K':>6} taps nmaj geglu |  auto    t1     t4     t6     t7     t8     t9    t10   old7   old9  (TF/s)")
+    print(f"{'Z':>4} {'T_out':>7} {'N':>5} {'K':>6} taps nmaj geglu |  auto    t1     t4     t6     t7     t8     t9    t10    t11   old7   old9  (TF/s)")
     for k, op in seen.items():
         Z, T, N, K, taps, nmaj, geglu, st, gn, act = k
         fl = 2.0 * Z * T * N * K
         res = []
-        for tile in (0, 1, 4, 6, 7, 8, 9, 10, -7, -9):
+        for tile in (0, 1, 4, 6, 7, 8, 9, 10, 11, -7, -9):
             if tile in (2, 5) and nmaj:
                 res.append(float("nan"))
                 continue
-            if geglu and abs(tile) in (4, 5, 7, 10):
+            if geglu and abs(tile) in (4, 5, 7, 10, 11):
                 res.append(float("nan"))
                 continue
             o2 = ops.ConvOp(**dict(op.kw, tile=abs(tile), no_halo=5 if tile < 0 else op.kw.get("no_halo", False)))
