@@ -525,6 +525,7 @@ int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int k
       (rows_all * p.ld_res2 + p.N) * 4 >= lim)
     return 0;
   switch (tile) {
+    case 6: return launch_f32<TCfg<128, 128, 64, 64, 1, 3>>(p, stream, ksplit);
     case 7: return launch_f32<TCfg<64, 64, 32, 32, 1, 6>>(p, stream, ksplit);
     case 9: return launch_f32<TCfg<64, 128, 32, 64, 1, 4>>(p, stream, ksplit);
     case 10: return p.geglu ? 0 : launch_f32<TCfg<32, 64, 32, 32, 2, 6>>(p, stream, ksplit);
