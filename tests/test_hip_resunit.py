@@ -133,6 +133,63 @@ def test_resunit_matches_the_unfused_pair_and_rejects_bad_args(dev):
         ops.ResUnitOp(x=x, w1=w1, b1=b1, w2=w2, b2=b2, out=x, n_batch=B, T=T, C=C, k=k, dilation=d, slope=slope)()
 
 
+SHAPE_CLASSES = [
+    # (name, Z, heads, M, N, K, taps): every contraction shape class of the path, incl. the long-form attention
+    ("1x1 K=256", 1, 1, 640, 512, 256, 1),
+    ("linear K=512 (QKV / GEGLU width)", 1, 1, 512, 1024, 512, 1),
+    ("conv k3 K=1536", 2, 1, 333, 512, 512, 3),
+    ("linear K=2048 (o-proj / FF2)", 1, 1, 384, 512, 2048, 1),
+    ("conv k3 K=3072 (up block on the concat)", 1, 1, 320, 512, 1024, 3),
+    ("conv k11 K=2816 (HiFi-GAN, C=256)", 1, 1, 512, 256, 256, 11),
+    ("Q K^T, L=1280, d=512", 1, 2, 1280, 1280, 512, 1),
+    ("P V, L=1280", 1, 2, 1280, 512, 1280, 1),
+    ("Q K^T, L=4352, d=512", 1, 1, 4352, 4352, 512, 1),
+    ("P V, L=4352", 1, 1, 4352, 512, 4352, 1),
+]
+
+
+@pytest.mark.parametrize("case", SHAPE_CLASSES, ids=[c[0] for c in SHAPE_CLASSES])
+def test_bf16x6_error_table_per_shape_class(dev, precision, case):
+    """fp32-faithfulness of bf16x6 per contraction shape class of the path (K = 256 ... 3072 over taps, the HiFi-GAN k 11
+    conv, Q K^T and P V at L = 1280 and 4352): max and rms error against fp64 must not exceed the exact-fp32 MFMA chain's
+    beyond summation-order noise.  P V's A operand is a softmax row (non-negative, sums to 1) as on the path."""
+    if precision != "fp32":
+        pytest.skip("one arm runs both modes")
+    name, Z, H, M, N, K, taps = case
+    att = "Q K^T" in name or "P V" in name
+    g = np.random.default_rng(abs(hash(name)) % 1000)
+    if "P V" in name:
+        a = torch.softmax(torch.from_numpy(g.standard_normal((Z, H, M, K)).astype(np.float32)) * 3.0, -1)
+        w = torch.from_numpy(g.standard_normal((Z, H, N, K)).astype(np.float32))
+    elif att:
+        a = torch.from_numpy(g.standard_normal((Z, H, M, K)).astype(np.float32))
+        w = torch.from_numpy(g.standard_normal((Z, H, N, K)).astype(np.float32))
+    else:
+        a = torch.from_numpy(g.standard_normal((Z, M, K)).astype(np.float32))
+        w = torch.from_numpy((g.standard_normal((N, K, taps)) / np.sqrt(K * taps)).astype(np.float32))
+    errs = {}
+    for mode in ("fp32", "bf16x6"):
+        serenade_amd.set_precision(mode)
+        if att:
+            out = torch.zeros(Z, H, M, N, device=dev)
+            ops.ConvOp(in0=a.to(dev), w=w.to(dev), out=out, n_batch=Z, n_head=H, T_in=M, T_out=M, C_in=K, N=N,
+                       in0_bs=H * M * K, in0_hs=M * K, ld_in0=K, w_bs=H * N * K, w_hs=N * K, ldw=K, out_bs=H * M * N,
+                       out_hs=M * N, ld_out=N, alpha=1.0 / np.sqrt(K) if "Q K^T" in name else 1.0)()
+            ref = torch.einsum("zhmk,zhnk->zhmn", a.double(), w.double()) * (1.0 / np.sqrt(K) if "Q K^T" in name else 1.0)
+        else:
+            out = torch.zeros(Z, M, N, device=dev)
+            ops.ConvOp(in0=a.to(dev), w=ops.pack_conv_weight(w.to(dev)), out=out, n_batch=Z, T_in=M, T_out=M, C_in=K, N=N,
+                       in0_bs=M * K, ld_in0=K, ldw=taps * K, out_bs=M * N, ld_out=N, taps=ops.conv_taps(taps))()
+            ref = F.conv1d(a.double().transpose(1, 2), w.double(), padding=(taps - 1) // 2).transpose(1, 2)
+        torch.cuda.synchronize()
+        d = out.cpu().double() - ref
+        errs[mode] = (d.abs().max().item() / ref.abs().max().item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item())
+    serenade_amd.set_precision("fp32")
+    print(f"{name}: relative max / rms error vs fp64  fp32 {errs['fp32'][0]:.2e} / {errs['fp32'][1]:.2e}   "
+          f"bf16x6 {errs['bf16x6'][0]:.2e} / {errs['bf16x6'][1]:.2e}")
+    assert errs["bf16x6"][0] <= 1.5 * errs["fp32"][0] + 1e-9 and errs["bf16x6"][1] <= 1.25 * errs["fp32"][1] + 1e-10, errs
+
+
 class Mirror:
     """CPU tensors <-> device clones, so one kw dict drives the kernel and the spec"""
 
