@@ -506,7 +506,7 @@ int launch_f32(const SrnConvParams& p, hipStream_t stream, const int ksplit) {
 }  // namespace
 
 // Returns 1 if the launch was handled, 0 if the shape is not eligible (the caller goes on to conv_fast.hip), < 0 on
-// error.  `p` has been validated and defaulted by srn_conv_gemm.  Tile ids: 7 = 64 x 64, 9 = 64 x 128 (conv_fast.hip's
+// error.  `p` has been validated and defaulted by srn_conv_gemm.  Tile ids: 5 = 128 x 32, 6 = 128 x 128, 7 = 64 x 64, 9 = 64 x 128 (conv_fast.hip's
 // single-stage ids, same results bit for bit), 10 = 32 x 64 with the step split over two wave pairs, 11 = 64 x 64 with
 // two register sets (loads two steps ahead: small grids and split-K slices, where a workgroup is alone on its CU).
 int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int ksplit) {
@@ -525,6 +525,7 @@ int srn_conv_f32_try(const SrnConvParams& p, int tile, hipStream_t stream, int k
       (rows_all * p.ld_res2 + p.N) * 4 >= lim)
     return 0;
   switch (tile) {
+    case 5: return p.geglu ? 0 : launch_f32<TCfg<128, 32, 32, 32, 1, 6>>(p, stream, ksplit);  // thin outputs (N = 32)
     case 6: return launch_f32<TCfg<128, 128, 64, 64, 1, 3>>(p, stream, ksplit);
     case 7: return launch_f32<TCfg<64, 64, 32, 32, 1, 6>>(p, stream, ksplit);
     case 9: return launch_f32<TCfg<64, 128, 32, 64, 1, 4>>(p, stream, ksplit);

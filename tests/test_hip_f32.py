@@ -74,7 +74,7 @@ def cases():
                                    out_bs=H * L * L, out_hs=L * L, ld_out=L, alpha=0.125)
 
 
-@pytest.mark.parametrize("tile", [7, 9, 11])
+@pytest.mark.parametrize("tile", [5, 6, 7, 9, 11])
 def test_bit_identical_to_conv_fast_fp32(dev, tile):
     for name, kw in cases():
         a = run(dev, kw, tile=tile)
