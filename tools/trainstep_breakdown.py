@@ -10,9 +10,9 @@ import sys
 
 
 def cat(n):
-    if "conv_fast" in n or "conv_gemm_kernel" in n or "splitk" in n or "conv_halo" in n:
+    if "conv_f32" in n or "conv_fast" in n or "conv_gemm_kernel" in n or "splitk" in n or "conv_halo" in n:
         return "own contraction kernels (srn_conv_gemm)"
-    if "tn_gemm" in n or "tn_reduce" in n:
+    if "tn_gemm" in n or "tn_lean" in n or "tn_reduce" in n:
         return "own time-contraction kernels (srn_tn_gemm: wgrad / dK / dV)"
     if n.startswith("Cijk") or "rocblas" in n:
         return "rocBLAS"
