@@ -154,6 +154,14 @@ int srn_resblock_tail(const float* c2, const float* gn_partials, const float* ga
                       float* y, int B, int T, int C, int groups, float gn_eps, float ln_eps, int valid_stats,
                       void* stream);
 
+/* The same, and in the same launch the LayerNorm that opens the transformer block behind every ResnetBlock1D
+ * (decoder.py:411-421 -> transformer.py:286, norm1):  y2 = LayerNorm(y; ln2_gamma, ln2_beta, ln2_eps), from the row still
+ * in registers (one HBM pass and one launch fewer per block; y2 equals srn_layernorm(y) bit for bit). */
+int srn_resblock_tail_ln(const float* c2, const float* gn_partials, const float* gamma, const float* beta,
+                         const int32_t* lens, const float* r, const float* scale, const float* shift, int64_t ld_ss,
+                         float* y, int B, int T, int C, int groups, float gn_eps, float ln_eps, int valid_stats,
+                         const float* ln2_gamma, const float* ln2_beta, float* y2, float ln2_eps, void* stream);
+
 /* nn.LayerNorm over the last dim (transformer.py:211,249): x, y (rows, C). */
 int srn_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps,
                   void* stream);

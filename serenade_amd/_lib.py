@@ -110,6 +110,8 @@ _SIGS = {
     "srn_gn_mish_apply": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "srn_resblock_tail": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int,
                                   c_float, c_float, c_int, _P]),
+    "srn_resblock_tail_ln": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int,
+                                     c_float, c_float, c_int, _P, _P, _P, c_float, _P]),
     "srn_scatter_rows": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "srn_layernorm": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "srn_softmax_rows": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(
     const float* __restrict__ c2, const float* __restrict__ partials, const float* __restrict__ gamma,
     const float* __restrict__ beta, const int32_t* __restrict__ lens, const float* __restrict__ rres,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ld_ss, float* __restrict__ y, int T,
-    int C, int groups, float gn_eps, float ln_eps, int valid_stats) {
+    int C, int groups, float gn_eps, float ln_eps, int valid_stats, const float* __restrict__ ln2_gamma,
+    const float* __restrict__ ln2_beta, float* __restrict__ y2, float ln2_eps) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * TAIL_ROWS;
@@ -160,6 +161,40 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(
         o.z = (v[i].z - mean) / stdv * sc.z + sh.z;
         o.w = (v[i].w - mean) / stdv * sc.w + sh.w;
         *reinterpret_cast<float4*>(y + row + c) = o;
+        v[i] = o;
+      }
+    }
+    if (y2 != nullptr) {
+      // the transformer block's first LayerNorm (transformer.py:286) of the row just produced, from registers:
+      // layernorm_kernel's arithmetic, operation for operation
+      float sum2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < c4n) sum2 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      const float mean2 = wave_sum(sum2) * inv_c;
+      float sq2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        if (lane + 64 * i < c4n) {
+          const float dx = v[i].x - mean2, dy = v[i].y - mean2, dz = v[i].z - mean2, dw = v[i].w - mean2;
+          sq2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+      }
+      const float rstd2 = 1.0f / sqrtf(wave_sum(sq2) * inv_c + ln2_eps);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < c4n) {
+          const int c = c4 * 4;
+          const float4 ga = *reinterpret_cast<const float4*>(ln2_gamma + c);
+          const float4 be = *reinterpret_cast<const float4*>(ln2_beta + c);
+          float4 o;
+          o.x = (v[i].x - mean2) * rstd2 * ga.x + be.x;
+          o.y = (v[i].y - mean2) * rstd2 * ga.y + be.y;
+          o.z = (v[i].z - mean2) * rstd2 * ga.z + be.z;
+          o.w = (v[i].w - mean2) * rstd2 * ga.w + be.w;
+          *reinterpret_cast<float4*>(y2 + row + c) = o;
+        }
       }
     }
   }
@@ -473,7 +508,27 @@ extern "C" int srn_resblock_tail(const float* c2, const float* gn_partials, cons
                 "resblock_tail: need (C / groups) %% 32 == 0");
   dim3 grid((T + TAIL_ROWS - 1) / TAIL_ROWS, B);
   hipLaunchKernelGGL(resblock_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2, gn_partials, gamma, beta,
-                     lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats);
+                     lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats, nullptr, nullptr,
+                     nullptr, 0.f);
+  SRN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int srn_resblock_tail_ln(const float* c2, const float* gn_partials, const float* gamma, const float* beta,
+                                    const int32_t* lens, const float* r, const float* scale, const float* shift,
+                                    int64_t ld_ss, float* y, int B, int T, int C, int groups, float gn_eps,
+                                    float ln_eps, int valid_stats, const float* ln2_gamma, const float* ln2_beta,
+                                    float* y2, float ln2_eps, void* stream) {
+  SRN_CHECK_ARG(c2 && gn_partials && gamma && beta && r && scale && shift && y && ln2_gamma && ln2_beta && y2,
+                "resblock_tail_ln: null pointer");
+  SRN_CHECK_ARG(!valid_stats || lens, "resblock_tail_ln: valid_stats needs lens");
+  SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "resblock_tail_ln: C=%d unsupported", C);
+  SRN_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
+                "resblock_tail_ln: need (C / groups) %% 32 == 0");
+  dim3 grid((T + TAIL_ROWS - 1) / TAIL_ROWS, B);
+  hipLaunchKernelGGL(resblock_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2, gn_partials, gamma, beta,
+                     lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats, ln2_gamma, ln2_beta,
+                     y2, ln2_eps);
   SRN_CHECK_LAUNCH();
   return 0;
 }

@@ -356,7 +356,9 @@ class DecoderPlan:
                           ld_out=kw.pop("ld_out", cout), bias=b, taps=taps, **kw)
 
         def resnet(ol, bi, k, lvl, xin, cin, ld_in, out, xin1=None, cin0=0):
+            # the block's tail also writes LayerNorm(out) for the transformer block that follows it (tfm skips its norm1)
             r = P["res"][bi]
+            t1 = P["tfm"][bi]
             T, C, ln = Ts[lvl], r["cout"], self.lens[lvl]
             extra = {}
             if xin1 is not None:
@@ -369,14 +371,15 @@ class DecoderPlan:
                                            bufA, B, T, C, tb_bs=tb_ld if self.per_sample_t else 0, valid_stats=rg))
             ol.append(conv(bufA, C, T, r["c2_w"], r["c2_b"], bufC, C, T, t3, gn_partials=gnp, **zero_pad))
             ol.append(conv(xin, cin, T, r["r_w"], r["r_b"], bufR, C, T, [0], ld_in=ld_in, len_in=ln, **extra))
-            ol.append(ops.resblock_tail_op(bufC, gnp, r["g2_w"], r["g2_b"], ln, bufR, (self.ss, ss_off[bi]),
-                                           (self.ss, ss_off[bi] + C), ss_ld, out, B, T, C, valid_stats=rg))
+            ol.append(ops.resblock_tail_ln_op(bufC, gnp, r["g2_w"], r["g2_b"], ln, bufR, (self.ss, ss_off[bi]),
+                                              (self.ss, ss_off[bi] + C), ss_ld, out, t1["ln1_w"], t1["ln1_b"], bufN, B, T, C,
+                                              valid_stats=rg))
 
         def tfm(ol, bi, lvl, X, C):
             t = P["tfm"][bi]
             T, ln = Ts[lvl], self.lens[lvl]
             Tp = _rup(T, 32)
-            ol.append(ops.layernorm_op(X, t["ln1_w"], t["ln1_b"], bufN, B * T, C))
+            # norm1(X) is already in bufN: the resnet block's tail wrote it (srn_resblock_tail_ln)
             # q | k row-major into qkv; the v third goes straight to V^T (transposed tail of the epilogue)
             ol.append(conv(bufN, C, T, t["qkv_w"], None, qkv, 3 * inner, T, [0], out_tr=Vt[T], out_tr_col0=2 * inner,
                            out_tr_bs=inner * Tp, ld_out_tr=Tp))

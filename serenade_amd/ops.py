@@ -346,6 +346,13 @@ def resblock_tail_op(c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y,
                                         gn_eps, ln_eps, int(bool(valid_stats))))
 
 
+def resblock_tail_ln_op(c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, ln_w, ln_b, y2, B, T, C, groups=8,
+                        gn_eps=1e-5, ln_eps=1e-5, valid_stats=False, ln2_eps=1e-5):
+    """resblock_tail_op + the LayerNorm that opens the transformer block behind it, in one launch"""
+    return CallOp("srn_resblock_tail_ln", (c2, partials, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups,
+                                           gn_eps, ln_eps, int(bool(valid_stats)), ln_w, ln_b, y2, ln2_eps))
+
+
 def scatter_rows_op(src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C):
     return CallOp("srn_scatter_rows", (src, src_bs, ld_src, dst, dst_bs, ld_dst, dc0, row_off, n_rows, B, T, C))
 

@@ -165,7 +165,10 @@ def emul_call(name, a):
             ln = T if lens is None else min(int(lens[b]), T)
             o[ln:] = 0
             yv[b] = o
-    elif name == "srn_resblock_tail":
+    elif name in ("srn_resblock_tail", "srn_resblock_tail_ln"):
+        ln2 = None
+        if name == "srn_resblock_tail_ln":
+            a, ln2 = a[:17], a[17:]
         c2, part, gamma, beta, lens, r, scale, shift, ld_ss, y, B, T, C, groups, ge, le, valid = a
         xv, rv, yv = (_v(t, B * T * C).reshape(B, T, C) for t in (c2, r, y))
         lens = None if lens is None else _v(lens)
@@ -180,6 +183,9 @@ def emul_call(name, a):
             mu = v.mean(dim=-1, keepdim=True)
             var = ((v - mu) ** 2).mean(dim=-1, keepdim=True)
             yv[b] = (v - mu) / (var + le).sqrt() * _v(scale)[b * ld_ss: b * ld_ss + C] + _v(shift)[b * ld_ss: b * ld_ss + C]
+        if ln2 is not None:
+            g2, b2, y2, e2 = ln2
+            _v(y2, B * T * C).reshape(B * T, C)[:] = F.layer_norm(yv.reshape(B * T, C), (C,), g2, b2, e2)
     elif name == "srn_layernorm":
         x, gamma, beta, y, rows, C, eps = a
         _v(y, rows * C).reshape(rows, C)[:] = F.layer_norm(_v(x, rows * C).reshape(rows, C), (C,), gamma, beta, eps)

@@ -353,6 +353,21 @@ def test_norm_and_elementwise_kernels(dev):
     e = _run_call(dev, "srn_resblock_tail", [xz, _partials(xz), gam, bet, lens, rnd(B, Tn, C, seed=38), (ss, C),
                                              (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5, 1])
     assert e < KTOL.k
+    # the fused form (tail + the transformer block's norm1 in one launch) against the spec, and bit for bit against the
+    # two separate launches
+    g2, b2 = 1 + 0.1 * rnd(C, seed=45), 0.1 * rnd(C, seed=46)
+    e = _run_call(dev, "srn_resblock_tail_ln", [x, _partials(x), gam, bet, lens, rnd(B, Tn, C, seed=38), (ss, C),
+                                                (ss, 2 * C), 4 * C, torch.zeros(B, Tn, C), B, Tn, C, 8, 1e-5, 1e-5, 0,
+                                                g2, b2, torch.zeros(B, Tn, C), 1e-5])
+    assert e < KTOL.k
+    d = lambda t: t.to(dev)
+    args = (d(x), d(_partials(x)), d(gam), d(bet), d(lens), d(rnd(B, Tn, C, seed=38)), (d(ss), C), (d(ss), 2 * C), 4 * C)
+    y_a, y_b, n_a, n_b = (torch.zeros(B, Tn, C, device=dev) for _ in range(4))
+    ops.resblock_tail_op(*args[:8], args[8], y_a, B, Tn, C)()
+    ops.layernorm_op(y_a, d(g2), d(b2), n_a, B * Tn, C)()
+    ops.resblock_tail_ln_op(*args[:8], args[8], y_b, d(g2), d(b2), n_b, B, Tn, C)()
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_b) and torch.equal(n_a, n_b)
     src = rnd(2, 9, 5, seed=44)
     e = _run_call(dev, "srn_scatter_rows", [src, 45, 5, torch.zeros(2, 16, 8), 128, 8, 2,
                                             torch.tensor([3, 7], dtype=torch.int32),
