@@ -40,7 +40,8 @@ def main():
         f"| CPU oracle on the host, {cb['cores']} threads / 1 thread (same utterance, T = 1024) | {f(cb['value'])} / "
         f"{f(cb['one_thread']['value'], 1)} | | | |",
         "",
-        f"Round 3's headline was 57 705 frames/s = 0.726 (kernel time).  HBM-side traffic of the contraction kernels: "
+        f"Round 3's headline was 57 705 frames/s = 0.726 (kernel time); this round's builds measured 59.7–62.5 k frames/s "
+        f"(0.76–0.79) across the boxes they ran on.  HBM-side traffic of the contraction kernels: "
         + (f"{tr / 1e6:.0f} MB per launch against {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic "
            f"({tr / r['algorithmic_bytes_per_launch']:.2f}×; `{r['traffic_record']['source']}`, measured on build "
            f"`{r['traffic_record']['measured_on_build']}`)." if tr else "not recorded for this build."),
