@@ -33,6 +33,7 @@ __device__ __attribute__((aligned(256))) float g_zero_page[64];
 
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // x = hi + lo, both round-to-nearest bf16; 5 VALU per pair
@@ -366,9 +367,27 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
   const int wn0 = (wave % C::WAVES_N) * C::WN;
   const int li = lane & 31;
   const int lh = lane >> 5;
-  const int sw = (li >> 2) & 3;  // row swizzle key (tile row offsets are multiples of 32)
-  const int fr_a = (wm0 + li) * 64;
-  const int fr_b = (wn0 + li) * 64;
+
+  // Split-bf16 modes multiply on v_mfma_f32_16x16x32_bf16 (round 2 measured it clocking ~6 % higher than 32x32x16 at the
+  // board's power cap): the wave's tile is (2 MT) x (2 NT) blocks of 16 x 16, one MFMA per block, plane pair and 32-deep
+  // step.  Lane l feeds row (l & 15), k chunk (l >> 4) of a block.  Block rows are taken in the order rho(j) = 4 pi(j >> 2)
+  // + (j & 3), pi = (0, 3, 2, 1): with the image's XOR swizzle (chunk ^ row quad) that makes every ds_read_b128 of a
+  // fragment conflict-free (identity order is 2-way).  After the loop the 4-register block accumulators are permuted into
+  // the 32 x 32 MFMA's C/D layout (two ds_bpermute + a select per register), so epilogue and split-K store are shared.
+  constexpr bool M16 = C::PREC != 0;
+  constexpr int RB = M16 ? 2 * MT : 1, CB = M16 ? 2 * NT : 1;
+  f32x4m acc4[RB][CB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc4[i][j][r] = 0.f;
+  const int l15 = lane & 15;
+  const int q15 = l15 >> 2;
+  const int piq = q15 == 1 ? 3 : (q15 == 3 ? 1 : q15);
+  const int rho15 = 4 * piq + (l15 & 3);
+  const int f16_off = rho15 * 64 + ((((lane >> 4) ^ piq) & 3) << 4);  // byte offset of this lane's fragment inside a block
 
   auto compute = [&](const int stage) {
     const unsigned char* sa_hi = smem_f + stage * C::STAGE;
@@ -404,29 +423,29 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
       }
       return;
     }
+    {
+      bf16x8 ah[RB], al[RB], bh[CB], bl[CB];
+      const unsigned char* pa = sa_hi + wm0 * 64 + f16_off;
+      const unsigned char* pb = sb_hi + wn0 * 64 + f16_off;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const int choff = (((kk * 2 + lh) ^ sw) & 3) << 4;
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        ah[m] = *reinterpret_cast<const bf16x8*>(sa_hi + fr_a + m * 2048 + choff);
-        al[m] = *reinterpret_cast<const bf16x8*>(sa_lo + fr_a + m * 2048 + choff);
+      for (int i = 0; i < RB; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 1024);
+        al[i] = *reinterpret_cast<const bf16x8*>(pa + (NPL - 1) * BM * 64 + i * 1024);
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        bh[n] = *reinterpret_cast<const bf16x8*>(sb_hi + fr_b + n * 2048 + choff);
-        bl[n] = *reinterpret_cast<const bf16x8*>(sb_lo + fr_b + n * 2048 + choff);
+      for (int j = 0; j < CB; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 1024);
+        bl[j] = *reinterpret_cast<const bf16x8*>(pb + (NPL - 1) * BN * 64 + j * 1024);
       }
-#define SRN_MFMA_GROUP(A_, B_)                                                                   \
-  _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n) \
-      acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[m], B_[n], acc[m][n], 0, 0, 0);
+#define SRN_MFMA_GROUP(A_, B_)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < RB; ++i) _Pragma("unroll") for (int j = 0; j < CB; ++j) \
+      acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[i], B_[j], acc4[i][j], 0, 0, 0);
       if constexpr (NPL == 3) {
-        bf16x8 am[MT], bm[NT];
+        bf16x8 am[RB], bm[CB];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) am[m] = *reinterpret_cast<const bf16x8*>(sa_hi + BM * 64 + fr_a + m * 2048 + choff);
+        for (int i = 0; i < RB; ++i) am[i] = *reinterpret_cast<const bf16x8*>(pa + BM * 64 + i * 1024);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bm[n] = *reinterpret_cast<const bf16x8*>(sb_hi + BN * 64 + fr_b + n * 2048 + choff);
+        for (int j = 0; j < CB; ++j) bm[j] = *reinterpret_cast<const bf16x8*>(pb + BN * 64 + j * 1024);
         // smallest terms first: 2^-16 (lo*hi, hi*lo, mid*mid), 2^-8 (mid*hi, hi*mid), 1 (hi*hi)
         SRN_MFMA_GROUP(al, bh)
         SRN_MFMA_GROUP(ah, bl)
@@ -452,8 +471,8 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     store(ss, Rs);
     load_issue(Rl);
     constexpr bool F32 = C::PREC == 0;
-    constexpr int N_MFMA = MT * NT * (F32 ? 16 : 3 * (NPL - 1));
-    constexpr int N_DSR = F32 ? (MT + NT) * 4 : (MT + NT) * 2 * NPL;
+    constexpr int N_MFMA = MT * NT * (F32 ? 16 : 4 * 3 * (NPL - 1));  // split modes: 4 blocks of 16 x 16 per 32 x 32
+    constexpr int N_DSR = F32 ? (MT + NT) * 4 : (MT + NT) * 2 * NPL;  // one b128 per 16-row block and plane
     constexpr int N_LD = C::A_LD + C::B_LD + B_LD2;
     constexpr int SPL = NPL == 3 ? 16 : 10;  // VALU of one float4 split
     constexpr int N_VALU = F32 ? C::A_LD * (ACT == SRN_ACT_NONE ? 0 : 8) + N_LD
@@ -476,6 +495,35 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     cursor_advance();
   };
 
+
+  // 16 x 16 block accumulators -> the 32 x 32 MFMA's C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)):
+  // element (row, col) of a 32 x 32 sub-tile sits in block (row >> 4, col >> 4), register row & 3, lane rho(col & 15) +
+  // 16 pi((row & 15) >> 2)
+  auto to_32x32 = [&]() {
+    if constexpr (M16) {
+      const int src_lo = rho15;  // rho(lane & 15)
+      const int qa = lh, qb = 2 + lh;  // (row & 15) >> 2 for r >> 2 even / odd
+      const int pqa = qa == 1 ? 3 : (qa == 3 ? 1 : qa), pqb = qb == 1 ? 3 : (qb == 3 ? 1 : qb);
+      const int addr_a = (src_lo + 16 * pqa) * 4, addr_b = (src_lo + 16 * pqb) * 4;
+      const bool right = (lane >> 4) & 1;  // this lane's column is in the right-hand 16 x 16 block
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int bi = 2 * m + (r >> 3);
+            const int addr = ((r >> 2) & 1) ? addr_b : addr_a;
+            // (the element goes through a scalar first: __builtin_bit_cast applied to the vector element itself
+            // picked the wrong register on this hipcc -- tools/experiments/mfma16_check2.hip)
+            const float x0 = acc4[bi][2 * n][r & 3], x1 = acc4[bi][2 * n + 1][r & 3];
+            const int v0 = __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x0));
+            const int v1 = __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x1));
+            acc[m][n][r] = __builtin_bit_cast(float, right ? v1 : v0);
+          }
+    }
+  };
+
   if constexpr (C::NSTAGE == 1) {
     // One LDS stage, one register set: [split / write tile s | barrier | loads of tile s+1 issued, MFMAs of tile s |
     // barrier].  Nothing overlaps inside the workgroup; three co-resident workgroups overlap each other.
@@ -489,6 +537,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
       cursor_advance();
       __syncthreads();
     }
+    to_32x32();
     if (ksplit > 1) splitk_store<MT, NT>(p, acc, slice, z, t0, n0, wm0, wn0, lane);
     else conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
     return;
@@ -518,6 +567,7 @@ __global__ __launch_bounds__(256, C::MIN_BLOCKS) void conv_fast_kernel(const Srn
     compute(1);
   }
 
+  to_32x32();
   if (ksplit > 1) splitk_store<MT, NT>(p, acc, slice, z, t0, n0, wm0, wn0, lane);
   else conv_epilogue<MT, NT>(p, acc, zb, zh, t0, n0, wm0, wn0, lane);
 }
