@@ -81,7 +81,7 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
         e[3].record()
         torch.cuda.synchronize()
         if it == 0:
-            loss0 = float(loss)
+            loss0 = float(loss.detach())
             t0 = time.perf_counter()
         else:
             for k, (a, b) in zip(phases, ((0, 1), (1, 2), (2, 3))):
@@ -112,7 +112,7 @@ def train_step_bench(dev, sd, B=4, L=1024, steps=3):
             "dropout_timed_at": 0.05,
             "dropout_validated_at": 0.0,  # the reference's mask draws cannot be reproduced: gradient parity runs use p = 0
             "parameters": int(sum(v.numel() for v in model.params.values())), **phases,
-            "loss_first": loss0, "loss_last": float(loss), "captured_as_hipgraph": graphed,
+            "loss_first": loss0, "loss_last": float(loss.detach()), "captured_as_hipgraph": graphed,
             "peak_hbm_gib": (torch.cuda.max_memory_allocated(dev) - base) / 2**30}
 
 

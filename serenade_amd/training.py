@@ -1442,14 +1442,17 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.g1, self.g2 = torch.cuda.CUDAGraph(keep_graph=True), None
+        # captured on the warm-up's stream: the leaves' gradient accumulators were created there (the estimator keeps
+        # re-laid weights that hold them), and autograd warns -- and synchronises -- when a later backward feeds them
+        # from another stream
         if self.split:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, stream=side):
                 self._fwd_bwd()
             self.g2 = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            with torch.cuda.graph(self.g2, pool=self.g1.pool(), stream=side):
                 opt.step_captured()
         else:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, stream=side):
                 self._fwd_bwd()
                 opt.step_captured()
         # a captured memset replays with a corrupted fill value on this stack (count_memset_nodes): a torch reduction

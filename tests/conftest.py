@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a backward fed from another stream than the one its gradient accumulators were made on costs a synchronisation
+    # per leaf and can break a capture: the captured training step must not do it (GraphedStep captures on its warm-up
+    # stream)
+    config.addinivalue_line("filterwarnings", "error:The AccumulateGrad node's stream does not match:UserWarning")
 
 
 @pytest.fixture(scope="session")
