@@ -221,12 +221,21 @@ class TransposeMultiOp:
 _TN_WS = {}
 
 
+_TN_OUTGROWN = []
+
+
 def tn_workspace(device, nbytes):
-    """slices of a time-sliced srn_tn_gemm: per (device, stream) like the split-K slab, grown on demand"""
+    """slices of a time-sliced srn_tn_gemm: per (device, stream) like the split-K slab, grown on demand.  An outgrown
+    slab is kept alive, not freed: a captured graph (training.GraphedStep) may have its address baked in, and the ops
+    that took it are transient.  Growth is by doubling at least, so the kept slabs sum to less than the live one."""
     stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
     key = (str(device), stream)
-    if key not in _TN_WS or _TN_WS[key].numel() < nbytes:
-        _TN_WS[key] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    old = _TN_WS.get(key)
+    if old is None or old.numel() < nbytes:
+        if old is not None:
+            _TN_OUTGROWN.append(old)
+        _TN_WS[key] = torch.empty(max(nbytes, 64 << 20, 2 * (old.numel() if old is not None else 0)),
+                                  dtype=torch.uint8, device=device)
     return _TN_WS[key]
 
 

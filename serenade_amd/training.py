@@ -82,8 +82,8 @@ class _Conv(torch.autograd.Function):
         assert lens is None or stride == 1
         ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the non-differentiable partial sums
         _launch_conv(x, w, bias, y, taps, B, T, T_out, C, N, in_stride=stride, gn_partials=part, len_in=lens)
-        ctx.save_for_backward(x, w)
-        ctx.taps, ctx.stride, ctx.has_bias, ctx.lens, ctx.wd = tuple(taps), stride, bias is not None, lens, wd
+        ctx.save_for_backward(x, w, wd)  # wd too: a re-laid buffer of the estimator, version-checked like w
+        ctx.taps, ctx.stride, ctx.has_bias, ctx.lens = tuple(taps), stride, bias is not None, lens
         if want_gn:
             ctx.mark_non_differentiable(part)
             return y, part
@@ -93,7 +93,7 @@ class _Conv(torch.autograd.Function):
     def backward(ctx, dy, *_):
         if dy is None:
             return (None,) * 9
-        x, w = ctx.saved_tensors
+        x, w, wd_saved = ctx.saved_tensors
         taps, stride, lens = ctx.taps, ctx.stride, ctx.lens
         B, T, C = x.shape
         _, T_out, N = dy.shape
@@ -104,8 +104,8 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dgrad: dX[t] = sum_j dY[(t - taps[j]) / stride] W_j over the taps that divide -> a conv of dY with the
             # transposed weights Wd[c][j][n] = W[n][j][c]; with stride 2 one launch per output-row parity
-            if ctx.wd is not None:  # re-laid once for the whole step (Estimator._relay)
-                wd = ctx.wd.view(C, nt, N)
+            if wd_saved is not None:  # re-laid once for the whole step (Estimator._relay)
+                wd = wd_saved.view(C, nt, N)
             else:
                 wd = torch.empty(C, nt, N, device=dy.device, dtype=torch.float32)  # LDS tile transposes, one batch per tap
                 _call("srn_transpose_ct", w, wd, nt, N, C, C, nt * C, N, nt * N)
@@ -219,6 +219,10 @@ class _PackAll(torch.autograd.Function):
     def forward(ctx, est, *weights):
         for op in est._relay_ops:
             op()
+        # the launches above rewrote the persistent buffers through raw pointers: tell autograd, so that a backward of an
+        # EARLIER forward (which saved aliases of them) raises instead of mixing its activations with these weights
+        for t in (*est._pk.values(), *est._wd.values()):
+            torch.autograd.graph.increment_version(t)
         ctx.est = est
         return tuple(est._pk[name].detach() for name in est._pack_names)  # fresh aliases: apply() marks its outputs
 

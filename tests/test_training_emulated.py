@@ -254,3 +254,20 @@ def test_overwrite_gradient_path_equals_accumulation():
         b.zero_grad()
         loss(b).backward()
     assert torch.equal(a.flat_grad, b.flat_grad) and not a.params["p1"].grad.any()
+
+
+def test_backward_after_a_second_forward_raises():
+    """the estimator re-lays its conv weights into persistent buffers once per forward (Estimator._relay): a backward of
+    an EARLIER forward would multiply its saved activations with the newer buffers -- autograd's version check catches
+    it because _PackAll bumps the buffers' version"""
+    w = sub(serenade_weights(), "cfm_decoder.estimator.")
+    x1, mask, mu, spk, mask_l, t, z = _case()
+    with _emulator.installed():
+        est = training.Estimator(w, torch.device("cpu"))
+        first, _ = training.cfm_loss(est, x1, mask, mu, spk, mask_l, draws={"t": t, "z": z})
+        second, _ = training.cfm_loss(est, x1, mask, mu, spk, mask_l, draws={"t": t, "z": z})
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            first.backward()
+        est.zero_grad()
+        second.backward()  # the latest forward is fine
+    assert est.params["final_proj.weight"].grad.abs().max() > 0
