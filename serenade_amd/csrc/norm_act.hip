@@ -44,6 +44,8 @@ __device__ __forceinline__ void group_stats(const float* __restrict__ partials, 
 }
 
 constexpr int GN_ROWS = 8;  // rows per workgroup (small: every workgroup first re-reduces the group statistics, more of them overlap that prefix)
+constexpr int SMALL_GRID = 512;  // workgroups below which the row kernels take half as many rows each (B = 1: latency, not bandwidth)
+constexpr int GN_PRE = 4;   // float4 per thread fetched ahead of the statistics (GN_ROWS rows of 512 channels)
 
 __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ partials,
@@ -52,24 +54,34 @@ __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restr
                                                             const float* __restrict__ time_bias,
                                                             const int32_t* __restrict__ lens, float* __restrict__ y,
                                                             int T, int C, int groups, float eps, int64_t tb_bs,
-                                                            int valid_stats) {
+                                                            int valid_stats, int rows_per_wg) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
-  const int r0 = blockIdx.x * GN_ROWS;
+  const int r0 = blockIdx.x * rows_per_wg;
   if (time_bias) time_bias += (int64_t)b * tb_bs;
   const int len = lens ? min(lens[b], T) : T;
-  group_stats(partials, b, T, C, groups, eps, s_mean, s_rstd, valid_stats ? len : T);
   const int c4n = C / 4;
   const int cpg = C / groups;
-  const int rows = min(GN_ROWS, T - r0);
+  const int rows = min(rows_per_wg, T - r0);
   const int total = rows * c4n;
   const int64_t base = ((int64_t)b * T + r0) * C;
-  for (int idx = threadIdx.x; idx < total; idx += 256) {
+  // the rows' values are on their way while the statistics are reduced (one memory round trip instead of two in a row)
+  float4 pre[GN_PRE];
+#pragma unroll
+  for (int k = 0; k < GN_PRE; ++k) {
+    const int idx = threadIdx.x + 256 * k;
+    pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total) {
+      const int r = idx / c4n;
+      if (r0 + r < len) pre[k] = *reinterpret_cast<const float4*>(x + base + (int64_t)r * C + (idx - r * c4n) * 4);
+    }
+  }
+  group_stats(partials, b, T, C, groups, eps, s_mean, s_rstd, valid_stats ? len : T);
+  auto one = [&](const int idx, const float4 v) {
     const int r = idx / c4n;
     const int c = (idx - r * c4n) * 4;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + r < len) {
-      const float4 v = *reinterpret_cast<const float4*>(x + base + (int64_t)r * C + c);
       const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
       const float4 be = *reinterpret_cast<const float4*>(beta + c);
       const int g = c / cpg;
@@ -87,6 +99,15 @@ __global__ __launch_bounds__(256) void gn_mish_apply_kernel(const float* __restr
       }
     }
     *reinterpret_cast<float4*>(y + base + (int64_t)r * C + c) = o;
+  };
+#pragma unroll
+  for (int k = 0; k < GN_PRE; ++k)
+    if ((int)threadIdx.x + 256 * k < total) one(threadIdx.x + 256 * k, pre[k]);
+  for (int idx = threadIdx.x + 256 * GN_PRE; idx < total; idx += 256) {
+    const int r = idx / c4n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < len) v = *reinterpret_cast<const float4*>(x + base + (int64_t)r * C + (idx - r * c4n) * 4);
+    one(idx, v);
   }
 }
 
@@ -100,17 +121,34 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(
     const float* __restrict__ beta, const int32_t* __restrict__ lens, const float* __restrict__ rres,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ld_ss, float* __restrict__ y, int T,
     int C, int groups, float gn_eps, float ln_eps, int valid_stats, const float* __restrict__ ln2_gamma,
-    const float* __restrict__ ln2_beta, float* __restrict__ y2, float ln2_eps) {
+    const float* __restrict__ ln2_beta, float* __restrict__ y2, float ln2_eps, int rows_per_wg) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.y;
-  const int r0 = blockIdx.x * TAIL_ROWS;
+  const int r0 = blockIdx.x * rows_per_wg;
   const int len = lens ? min(lens[b], T) : T;
-  group_stats(partials, b, T, C, groups, gn_eps, s_mean, s_rstd, valid_stats ? len : T);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c4n = C / 4;
   const int cpg = C / groups;
   const float inv_c = 1.0f / (float)C;
-  for (int r = r0 + wave; r < min(r0 + TAIL_ROWS, T); r += 4) {
+  const int r_end = min(r0 + rows_per_wg, T);
+  // a wave's row is on its way while the statistics are reduced (one memory round trip instead of two in a row)
+  float4 xin[MAXV], rin[MAXV];
+  auto fetch = [&](const int r) {
+    const int64_t row = ((int64_t)b * T + r) * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + 64 * i;
+      xin[i] = rin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < c4n) {
+        rin[i] = *reinterpret_cast<const float4*>(rres + row + c4 * 4);
+        if (r < len) xin[i] = *reinterpret_cast<const float4*>(c2 + row + c4 * 4);
+      }
+    }
+  };
+  if (r0 + wave < r_end) fetch(r0 + wave);
+  group_stats(partials, b, T, C, groups, gn_eps, s_mean, s_rstd, valid_stats ? len : T);
+  for (int r = r0 + wave; r < r_end; r += 4) {
+    if (r != r0 + wave) fetch(r);
     const int64_t row = ((int64_t)b * T + r) * C;
     const bool valid = r < len;
     float4 v[MAXV];
@@ -121,10 +159,10 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c4 < c4n) {
         const int c = c4 * 4;
-        const float4 rr = *reinterpret_cast<const float4*>(rres + row + c);
+        const float4 rr = rin[i];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) {
-          const float4 x = *reinterpret_cast<const float4*>(c2 + row + c);
+          const float4 x = xin[i];
           const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
           const float4 be = *reinterpret_cast<const float4*>(beta + c);
           const int g = c / cpg;
@@ -490,9 +528,10 @@ extern "C" int srn_gn_mish_apply(const float* x, const float* gn_partials, const
   SRN_CHECK_ARG(!valid_stats || lens, "gn_mish_apply: valid_stats needs lens");
   SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
                 "gn_mish_apply: need (C / groups) %% 32 == 0 (C=%d groups=%d)", C, groups);
-  dim3 grid((T + GN_ROWS - 1) / GN_ROWS, B);
+  const int rows_per_wg = (int64_t)B * ((T + GN_ROWS - 1) / GN_ROWS) < SMALL_GRID ? GN_ROWS / 2 : GN_ROWS;
+  dim3 grid((T + rows_per_wg - 1) / rows_per_wg, B);
   hipLaunchKernelGGL(gn_mish_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gn_partials, gamma, beta,
-                     time_bias, lens, y, T, C, groups, eps, time_bias_bs, valid_stats);
+                     time_bias, lens, y, T, C, groups, eps, time_bias_bs, valid_stats, rows_per_wg);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -506,10 +545,11 @@ extern "C" int srn_resblock_tail(const float* c2, const float* gn_partials, cons
   SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "resblock_tail: C=%d unsupported", C);
   SRN_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
                 "resblock_tail: need (C / groups) %% 32 == 0");
-  dim3 grid((T + TAIL_ROWS - 1) / TAIL_ROWS, B);
+  const int rows_per_wg = (int64_t)B * ((T + TAIL_ROWS - 1) / TAIL_ROWS) < SMALL_GRID ? TAIL_ROWS / 2 : TAIL_ROWS;
+  dim3 grid((T + rows_per_wg - 1) / rows_per_wg, B);
   hipLaunchKernelGGL(resblock_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2, gn_partials, gamma, beta,
                      lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats, nullptr, nullptr,
-                     nullptr, 0.f);
+                     nullptr, 0.f, rows_per_wg);
   SRN_CHECK_LAUNCH();
   return 0;
 }
@@ -525,10 +565,11 @@ extern "C" int srn_resblock_tail_ln(const float* c2, const float* gn_partials, c
   SRN_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C <= 256 * MAXV, "resblock_tail_ln: C=%d unsupported", C);
   SRN_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0 && (C / groups) % 32 == 0,
                 "resblock_tail_ln: need (C / groups) %% 32 == 0");
-  dim3 grid((T + TAIL_ROWS - 1) / TAIL_ROWS, B);
+  const int rows_per_wg = (int64_t)B * ((T + TAIL_ROWS - 1) / TAIL_ROWS) < SMALL_GRID ? TAIL_ROWS / 2 : TAIL_ROWS;
+  dim3 grid((T + rows_per_wg - 1) / rows_per_wg, B);
   hipLaunchKernelGGL(resblock_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2, gn_partials, gamma, beta,
                      lens, r, scale, shift, ld_ss, y, T, C, groups, gn_eps, ln_eps, valid_stats, ln2_gamma, ln2_beta,
-                     y2, ln2_eps);
+                     y2, ln2_eps, rows_per_wg);
   SRN_CHECK_LAUNCH();
   return 0;
 }
