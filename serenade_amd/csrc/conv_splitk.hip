@@ -113,7 +113,10 @@ int srn_splitk_plan(const SrnConvParams& p) {
   if (steps < 24) return 1;
   const int64_t tiles = (int64_t)p.n_batch * p.n_head * ((p.T_out + 63) / 64) * ((p.N + 63) / 64);
   if (tiles > 192) return 1;
-  int ks = (int)(448 / tiles);  // ~1.75 workgroups per CU
+  // one workgroup per CU: conv_f32.hip's two-steps-ahead tile covers its own latency, and a second workgroup on a CU
+  // halves both's matrix rate (B = 1 x T = 256 in place, same box: 15.44-15.52 ms at 256, 15.67 at round 3's 448 -- the
+  // double-buffered conv_fast.hip tile wanted ~1.75 per CU --, 15.49 at 288, 16.0-16.3 at 192 / 224 / 320)
+  int ks = (int)(256 / tiles);
   ks = ks > MAX_KSPLIT ? MAX_KSPLIT : ks;
   ks = ks > steps / 4 ? steps / 4 : ks;  // at least four steps per slice
   if (ks < 2) return 1;
