@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU): sample rocm-smi clocks / power while a long GEMM loop runs."""
+"""Developer tool (GPU): sample rocm-smi clocks / power while a long GEMM loop runs, or (--convert B T) while whole
+conversions of B utterances x T frames (10 Euler steps + HiFi-GAN, exact fp32) run back to back."""
 import os
 import subprocess
 import sys
@@ -21,6 +22,25 @@ def main():
             (_lib.PREC_BF16X6 if "--bf16x6" in sys.argv else _lib.PREC_BF16X3))
     op = ops.ConvOp(in0=x, w=w, out=out, n_batch=1, T_in=M, T_out=M, C_in=K, N=N, ld_in0=K, ldw=K, ld_out=N,
                     precision=prec, tile=int(os.environ.get("SRN_TILE", "1")))
+    label = None
+    if "--convert" in sys.argv:
+        import bench
+        import serenade_amd
+        from serenade_amd.utils.synth import synth_inputs
+        i = sys.argv.index("--convert")
+        B, T = int(sys.argv[i + 1]), int(sys.argv[i + 2])
+        serenade_amd.set_precision("fp32")
+        model, voc, _, _ = bench.build_models(dev)
+        g = {k: (v.to(dev) if v.is_floating_point() else v) for k, v in synth_inputs(B, T, T_ref=256, seed=1235).items()}
+
+        def op():
+            mel = model.inference(g["x"], g["lengths"], g["midi"], g["lft"], g["ref_x"], g["ref_lengths"], g["ref_logmel"],
+                                  g["ref_midi"], g["ref_lft"], noise=g["z"])
+            voc.decode_batch(mel if mel.dim() == 3 else mel.unsqueeze(0))
+        for _ in range(3):
+            op()
+        torch.cuda.synchronize()
+        label = f"conversions B={B} x T={T}, 10 Euler steps + HiFi-GAN, exact fp32"
     stop = False
     seen = {"sclk": [], "power": []}
 
@@ -43,17 +63,22 @@ def main():
     th.start()
     t0 = time.time()
     n = 0
+    per = 20 if label else 200
     while time.time() - t0 < 4.0:
-        for _ in range(200):
+        for _ in range(per):
             op()
         torch.cuda.synchronize()
-        n += 200
+        n += per
     el = time.time() - t0
     stop = True
     th.join()
     import statistics
     med = lambda v: statistics.median(v[1:]) if len(v) > 1 else (v[0] if v else float("nan"))
     name = {_lib.PREC_FP32: "fp32", _lib.PREC_BF16X3: "bf16x3", _lib.PREC_BF16X6: "bf16x6"}[prec]
+    if label:
+        print(f"SUMMARY {label}: {n} in {el:.2f} s -> {el / n * 1e3:.2f} ms each; median sclk {med(seen['sclk'])} MHz, "
+              f"median power {med(seen['power'])} W")
+        return
     print(f"SUMMARY {name} {M}x{N}x{K}: {n} launches in {el:.2f} s -> {el / n * 1e6:.1f} us each, "
           f"{2.0 * M * N * K * n / el / 1e12:.1f} TF/s; median sclk {med(seen['sclk'])} MHz, median power "
           f"{med(seen['power'])} W")
