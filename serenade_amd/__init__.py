@@ -44,5 +44,6 @@ def get_precision():
     return {v: k for k, v in _NAMES.items()}[ops.DEFAULT_PRECISION]
 
 
-set_precision(os.environ.get("SERENADE_AMD_PRECISION", "bf16x3"))
+# default: the reference's arithmetic (exact fp32); the split-bf16 modes are opt-in
+set_precision(os.environ.get("SERENADE_AMD_PRECISION", "fp32"))
 set_attention_precision(os.environ.get("SERENADE_AMD_ATTENTION_PRECISION") or None)

@@ -37,7 +37,7 @@ _ORACLE = {}
 def precision(request):
     serenade_amd.set_precision(request.param)
     yield request.param
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default
 
 
 @pytest.fixture(scope="module")

@@ -30,7 +30,7 @@ def dev():
 def fp32_mode():
     serenade_amd.set_precision("fp32")
     yield
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default
 
 
 def rnd(*s, seed=0):

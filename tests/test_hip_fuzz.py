@@ -18,7 +18,7 @@ def precision(request):
     serenade_amd.set_precision(request.param)
     KTOL.k = 1e-4 if request.param == "bf16x3" else 2e-5
     yield request.param
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default
 
 
 def make_case(seed):

@@ -41,7 +41,7 @@ def precision(request):
     _Tol.k = 1e-4 if request.param == "bf16x3" else 2e-5
     _Tol.model = MEL_RTOL if request.param == "bf16x3" else 1e-4
     yield request.param
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default
 
 
 def T(a):

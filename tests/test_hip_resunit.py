@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def precision(request):
     serenade_amd.set_precision(request.param)
     yield request.param
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default
 
 
 @pytest.fixture(scope="module")

@@ -82,4 +82,4 @@ def test_sifigan_gpu_default_config(precision):
     tol = 1e-4 if precision == "fp32" else 1e-3
     assert y.shape == (2, 1, 24 * 120)
     assert nerr(y, y_ref) < tol and nerr(e, e_ref) < tol
-    serenade_amd.set_precision("bf16x3")
+    serenade_amd.set_precision("fp32")  # the package default

@@ -386,7 +386,7 @@ def test_gpu_postprocessing_cli_end_to_end(tmp_path):
         frames = PP.main(["generator=sifigan", f"in_dir={tmp_path / 'results'}", f"stats={tmp_path / 'stats.joblib'}",
                           f"checkpoint_path={tmp_path / 'model.pkl'}", "noise_amp=0"])
     finally:
-        serenade_amd.set_precision("bf16x3")
+        serenade_amd.set_precision("fp32")  # the package default
     names = sorted(p.name for p in d.iterdir() if p.name.endswith("_sifigan.wav"))
     assert names == [f"{n}_sifigan.wav" for n in sorted(items)]
     w = fold_weight_norm(sd)

@@ -81,11 +81,11 @@ def main():
                       f"{2.0 * Z * To * N * K * cnt / ms / 1e9:6.1f} {100 * ms / tot:6.1f}%")
             for name, (cnt, ms) in sorted(other.items(), key=lambda kv: -kv[1][1]):
                 print(f"  {name:40s} cnt {cnt:3d}  {ms:7.3f} ms")
-            peak = 157.3 if os.environ.get("SERENADE_AMD_PRECISION", "bf16x3") == "fp32" else 2500.0
+            peak = 157.3 if os.environ.get("SERENADE_AMD_PRECISION", "fp32") == "fp32" else 2500.0
             print(json.dumps({"sifigan_generator": {"ms_per_batch": el * 1e3, "contraction_ms": tot, "algorithmic_gflop": fl / 1e9,
                                                     "roofline": {"bound": "mfma", "achieved": fl / tot / 1e9, "peak": peak,
                                                                  "unit": "TFLOP/s", "frac": fl / tot / 1e9 / peak},
-                                                    "precision": os.environ.get("SERENADE_AMD_PRECISION", "bf16x3")}}))
+                                                    "precision": os.environ.get("SERENADE_AMD_PRECISION", "fp32")}}))
 
 
 if __name__ == "__main__":
